@@ -1,0 +1,307 @@
+"""ctypes binding of libmaus_hip.so (include/maus_hip.h).
+
+The product path has no CPU fallback: if the HIP library cannot be loaded, or a
+device context cannot be created, this module raises -- it never routes the
+candidate step through NumPy/SciPy."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmaus_hip.so")
+
+# every symbol include/maus_hip.h declares (tests/test_cabi_symbols.py checks the list against the header)
+SYMBOLS = [
+    "maus_ctx_create", "maus_ctx_destroy", "maus_last_error", "maus_device_info", "maus_abi_version",
+    "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get",
+    "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_relax_normalise", "maus_residual",
+    "maus_svd_power_step", "maus_set_eigvecs", "maus_herm_match", "maus_gmres", "maus_jacobi_check",
+    "maus_zgemm_host", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
+    "maus_profile_enable", "maus_profile_read", "maus_sync", "maus_mt19937_jump",
+]
+
+POP_X, POP_U, POP_W, POP_Y = 0, 1, 2, 3
+KIND_EIG, KIND_LINEAR, KIND_SVD = 1, 2, 3
+PERT_NONE, PERT_UNIFORM, PERT_MT19937 = 0, 1, 2
+KC_NAMES = ["zgemm", "lu_panel", "trsm", "laswp", "build_h", "backsolve", "vector"]
+
+_lib = None
+
+
+class MausHipError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load libmaus_hip.so (built in-tree by __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MausHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the candidate step.")
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
+    i32p = C.POINTER(C.c_int32)
+    sig = {
+        "maus_ctx_create": ([C.c_int, C.POINTER(vp)], C.c_int),
+        "maus_ctx_destroy": ([vp], C.c_int),
+        "maus_last_error": ([vp], C.c_char_p),
+        "maus_device_info": ([vp, C.c_char_p, C.c_int, ip, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)], C.c_int),
+        "maus_abi_version": ([], C.c_int),
+        "maus_set_matrix": ([vp, vp, C.c_int, C.c_int], C.c_int),
+        "maus_set_rhs": ([vp, vp, C.c_int], C.c_int),
+        "maus_pop_reserve": ([vp, C.c_int], C.c_int),
+        "maus_pop_capacity": ([vp], C.c_int),
+        "maus_pop_put": ([vp, C.c_int, vp, C.c_int, vp, C.c_int], C.c_int),
+        "maus_pop_get": ([vp, C.c_int, vp, C.c_int, vp, C.c_int], C.c_int),
+        "maus_matvec_rayleigh": ([vp, vp, C.c_int, vp, vp], C.c_int),
+        "maus_shifted_lu_solve": ([vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp], C.c_int),
+        "maus_relax_normalise": ([vp, vp, C.c_int, vp, C.c_int, vp], C.c_int),
+        "maus_residual": ([vp, C.c_int, vp, C.c_int, vp, vp, vp], C.c_int),
+        "maus_svd_power_step": ([vp, vp, C.c_int, vp], C.c_int),
+        "maus_set_eigvecs": ([vp, vp, C.c_int], C.c_int),
+        "maus_herm_match": ([vp, vp, C.c_int, vp, vp], C.c_int),
+        "maus_gmres": ([vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_int, C.c_int, vp, vp, vp], C.c_int),
+        "maus_jacobi_check": ([vp, C.c_int, vp, vp, vp], C.c_int),
+        "maus_zgemm_host": ([vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int], C.c_int),
+        "maus_lu_solve_host": ([vp, C.c_int, C.c_int, vp, vp, vp, vp, vp], C.c_int),
+        "maus_timer_start": ([vp], C.c_int),
+        "maus_timer_stop": ([vp, C.POINTER(C.c_float)], C.c_int),
+        "maus_profile_enable": ([vp, C.c_int], C.c_int),
+        "maus_profile_read": ([vp, C.c_int, ip, dp, dp, dp], C.c_int),
+        "maus_sync": ([vp], C.c_int),
+        "maus_mt19937_jump": ([vp, i32p, C.c_uint64], C.c_int),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here == missing export: fail loudly
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def _c128(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.complex128)
+    if shape is not None:
+        assert a.shape == tuple(shape), (a.shape, shape)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One device context (one per GPU).  Thin, typed wrappers over the C ABI."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.maus_ctx_create(device, C.byref(h))
+        if rc != 0 or not h:
+            msg = self.lib.maus_last_error(None)
+            raise MausHipError(f"maus_ctx_create(device={device}) failed: {msg.decode() if msg else rc}; "
+                               "a MI355X (gfx950) device is required -- no CPU fallback exists")
+        self.h = h
+        self.device = device
+        self.rows = self.cols = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.maus_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            msg = self.lib.maus_last_error(self.h)
+            raise MausHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+    # -- info / measurement ------------------------------------------------
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus = C.c_int()
+        tot, fr = C.c_size_t(), C.c_size_t()
+        self._ck(self.lib.maus_device_info(self.h, name, 256, C.byref(cus), C.byref(tot), C.byref(fr)), "maus_device_info")
+        return {"name": name.value.decode(), "cus": cus.value, "hbm_total": tot.value, "hbm_free": fr.value}
+
+    def sync(self):
+        self._ck(self.lib.maus_sync(self.h), "maus_sync")
+
+    def timer_start(self):
+        self._ck(self.lib.maus_timer_start(self.h), "maus_timer_start")
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._ck(self.lib.maus_timer_stop(self.h, C.byref(ms)), "maus_timer_stop")
+        return float(ms.value)
+
+    def profile_enable(self, on=True):
+        self._ck(self.lib.maus_profile_enable(self.h, 1 if on else 0), "maus_profile_enable")
+
+    def profile_read(self):
+        out = {}
+        for k, name in enumerate(KC_NAMES):
+            n = C.c_int()
+            ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+            self._ck(self.lib.maus_profile_read(self.h, k, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "maus_profile_read")
+            out[name] = {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+        return out
+
+    # -- problem data --------------------------------------------------------
+    def set_matrix(self, A):
+        A = _c128(A)
+        assert A.ndim == 2
+        self.rows, self.cols = A.shape
+        self._ck(self.lib.maus_set_matrix(self.h, _ptr(A), A.shape[0], A.shape[1]), "maus_set_matrix")
+
+    def set_rhs(self, b):
+        b = _c128(b)
+        self._ck(self.lib.maus_set_rhs(self.h, _ptr(b), b.shape[0]), "maus_set_rhs")
+
+    def set_eigvecs(self, V):
+        V = _c128(V)
+        self._ck(self.lib.maus_set_eigvecs(self.h, _ptr(V), V.shape[0]), "maus_set_eigvecs")
+
+    # -- population ----------------------------------------------------------
+    def pop_reserve(self, cap):
+        self._ck(self.lib.maus_pop_reserve(self.h, int(cap)), "maus_pop_reserve")
+
+    def pop_capacity(self):
+        return self.lib.maus_pop_capacity(self.h)
+
+    @staticmethod
+    def _slots(slots):
+        return np.ascontiguousarray(slots, dtype=np.int32)
+
+    def pop_put(self, which, slots, vecs):
+        s = self._slots(slots)
+        v = _c128(vecs)
+        if v.ndim == 1:
+            v = v[None, :]
+        assert v.shape[0] == s.shape[0]
+        self._ck(self.lib.maus_pop_put(self.h, which, _ptr(s), s.shape[0], _ptr(v), v.shape[1]), "maus_pop_put")
+
+    def pop_get(self, which, slots, length):
+        s = self._slots(slots)
+        out = np.empty((s.shape[0], length), dtype=np.complex128)
+        self._ck(self.lib.maus_pop_get(self.h, which, _ptr(s), s.shape[0], _ptr(out), length), "maus_pop_get")
+        return out
+
+    # -- phases --------------------------------------------------------------
+    def matvec_rayleigh(self, slots):
+        s = self._slots(slots)
+        num = np.empty(s.shape[0], dtype=np.complex128)
+        den = np.empty(s.shape[0], dtype=np.complex128)
+        self._ck(self.lib.maus_matvec_rayleigh(self.h, _ptr(s), s.shape[0], _ptr(num), _ptr(den)), "maus_matvec_rayleigh")
+        return num, den
+
+    def shifted_lu_solve(self, slots, shift, psi, rhs_mode=0, pert_mode=PERT_NONE, pert_data=None):
+        s = self._slots(slots)
+        k = s.shape[0]
+        sh = _c128(shift, (k,))
+        ps = np.ascontiguousarray(psi, dtype=np.float64)
+        assert ps.shape == (k,)
+        status = np.zeros(k, dtype=np.int32)
+        pd = None
+        if pert_mode == PERT_UNIFORM:
+            pd = np.ascontiguousarray(pert_data, dtype=np.float64)
+            assert pd.shape == (k, 2, self.rows, self.rows), pd.shape
+        self._ck(self.lib.maus_shifted_lu_solve(self.h, _ptr(s), k, _ptr(sh), _ptr(ps), int(rhs_mode), int(pert_mode),
+                                                _ptr(pd), _ptr(status)), "maus_shifted_lu_solve")
+        return status
+
+    def relax_normalise(self, slots, alpha, normalise=True):
+        s = self._slots(slots)
+        al = _c128(alpha, (s.shape[0],))
+        nrm = np.empty(s.shape[0], dtype=np.float64)
+        self._ck(self.lib.maus_relax_normalise(self.h, _ptr(s), s.shape[0], _ptr(al), 1 if normalise else 0, _ptr(nrm)),
+                 "maus_relax_normalise")
+        return nrm
+
+    def residual(self, kind, slots, lam=None):
+        s = self._slots(slots)
+        l = None if lam is None else _c128(lam, (s.shape[0],))
+        res = np.empty(s.shape[0], dtype=np.float64)
+        fin = np.empty(s.shape[0], dtype=np.int32)
+        self._ck(self.lib.maus_residual(self.h, int(kind), _ptr(s), s.shape[0], _ptr(l), _ptr(res), _ptr(fin)), "maus_residual")
+        return res, fin.astype(bool)
+
+    def svd_power_step(self, slots):
+        s = self._slots(slots)
+        norms = np.empty((s.shape[0], 4), dtype=np.float64)
+        self._ck(self.lib.maus_svd_power_step(self.h, _ptr(s), s.shape[0], _ptr(norms)), "maus_svd_power_step")
+        return norms
+
+    def herm_match(self, slots):
+        s = self._slots(slots)
+        idx = np.empty(s.shape[0], dtype=np.int32)
+        nrm = np.empty(s.shape[0], dtype=np.float64)
+        self._ck(self.lib.maus_herm_match(self.h, _ptr(s), s.shape[0], _ptr(idx), _ptr(nrm)), "maus_herm_match")
+        return idx, nrm
+
+    def gmres(self, slots, shift, psi, rhs_mode, use_jacobi, rtol=1e-8, restart=20, maxiter=50):
+        s = self._slots(slots)
+        k = s.shape[0]
+        sh = _c128(shift, (k,))
+        ps = np.ascontiguousarray(psi, dtype=np.float64)
+        uj = np.ascontiguousarray(use_jacobi, dtype=np.int32)
+        info = np.zeros(k, dtype=np.int32)
+        inner = np.zeros(k, dtype=np.int32)
+        status = np.zeros(k, dtype=np.int32)
+        self._ck(self.lib.maus_gmres(self.h, _ptr(s), k, _ptr(sh), _ptr(ps), int(rhs_mode), _ptr(uj), float(rtol),
+                                     int(restart), int(maxiter), _ptr(info), _ptr(inner), _ptr(status)), "maus_gmres")
+        return info, inner, status
+
+    def jacobi_check(self, shift, psi):
+        sh = _c128(shift)
+        k = sh.shape[0]
+        ps = np.ascontiguousarray(psi, dtype=np.float64)
+        ok = np.zeros(k, dtype=np.int32)
+        self._ck(self.lib.maus_jacobi_check(self.h, k, _ptr(sh), _ptr(ps), _ptr(ok)), "maus_jacobi_check")
+        return ok.astype(bool)
+
+    # -- test / utility entry points ------------------------------------------
+    def zgemm(self, A, B, C_in=None, b_layout=0, conj_a=False, conj_b=False, alpha=1.0, beta=0):
+        A = _c128(A)
+        B = _c128(B)
+        M, K = A.shape
+        N = B.shape[0] if b_layout else B.shape[1]
+        Cm = np.zeros((M, N), dtype=np.complex128) if C_in is None else _c128(C_in).copy()
+        self._ck(self.lib.maus_zgemm_host(self.h, M, N, K, _ptr(A), _ptr(B), _ptr(Cm), int(b_layout), int(conj_a),
+                                          int(conj_b), float(alpha), int(beta)), "maus_zgemm_host")
+        return Cm
+
+    def lu_solve(self, A, b, want_ipiv=False):
+        A = _c128(A)
+        b = _c128(b)
+        if A.ndim == 2:
+            A = A[None]
+            b = b[None]
+        cnt, n, _ = A.shape
+        x = np.empty((cnt, n), dtype=np.complex128)
+        status = np.zeros(cnt, dtype=np.int32)
+        ipiv = np.zeros((cnt, n), dtype=np.int32) if want_ipiv else None
+        self._ck(self.lib.maus_lu_solve_host(self.h, cnt, n, _ptr(A), _ptr(b), _ptr(x), _ptr(status), _ptr(ipiv)), "maus_lu_solve_host")
+        return (x, status, ipiv) if want_ipiv else (x, status)
+
+
+def mt19937_jump(key: np.ndarray, pos: int, nwords: int):
+    """Advance a legacy NumPy MT19937 (key[624], pos) by nwords 32-bit outputs."""
+    lib = load_library()
+    k = np.ascontiguousarray(key, dtype=np.uint32).copy()
+    p = C.c_int32(int(pos))
+    rc = lib.maus_mt19937_jump(_ptr(k), C.byref(p), C.c_uint64(int(nwords)))
+    if rc != 0:
+        raise MausHipError("maus_mt19937_jump failed")
+    return k, int(p.value)

@@ -1,0 +1,566 @@
+// libmaus_hip C ABI (include/maus_hip.h): context, device memory, stream, and the batched
+// phases of the MAUS candidate step.  Host orchestration stays in Python (ctypes).
+#include "common.h"
+#include "../../include/maus_hip.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ---- kernels / drivers implemented in the other translation units ---------------------
+struct LuWs {
+    c128* H; long ldh; long strideH; int n; int npad; int G;
+    int* ipiv; int* info; int* flags;
+    hipStream_t st;
+    void (*tick)(void* ud, int klass, int phase, double flops, double bytes); void* ud;
+};
+void maus_lu_factor(const LuWs& w, int nbo);
+void maus_lu_backsolve(const LuWs& w, c128* Wpop, long ldw, const int* d_slots, c128* xout_dense);
+void maus_build_h(const LuWs& w, const c128* A, const c128* d_shift, const double* d_psi, int rhs_mode,
+                  const c128* X, long ldx, const int* d_slots, const c128* bvec, int pert_mode, const double* d_U);
+void maus_load_h(const LuWs& w, const c128* d_Ain, const c128* d_bin);
+int maus_lu_max_npad();
+void maus_zgemm_launch_idx(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,
+                           const c128* B, long ldb, long sB, c128* C, long ldc, long sC,
+                           double alpha, int beta, int batch, int blay, bool conja, bool conjb,
+                           const int* a_rows, const int* c_rows);
+void maus_launch_rayleigh_dots(hipStream_t st, const c128* X, const c128* Y, long ld, const int* slots, int count, int n, c128* num, c128* den);
+void maus_launch_relax(hipStream_t st, c128* X, const c128* W, long ld, const int* slots, int count, int n, const c128* alpha, int normalise, double* norm_out);
+void maus_launch_residual(hipStream_t st, int kind, const c128* X, const c128* Y, long ld, const int* slots, int count, int n,
+                          const c128* lam, const c128* bvec, double* resid, int* finite);
+void maus_launch_svd_resid(hipStream_t st, const c128* Yv, const c128* Uv, long ld, const int* slots, int count, int n,
+                           const c128* sigma, double* out, int accumulate, int* finite);
+void maus_launch_norm_scale(hipStream_t st, const c128* S, c128* D, long ld, const int* slots, int count, int n, double* norm_out, int stride_out, int off_out);
+void maus_launch_norm(hipStream_t st, const c128* S, long ld, const int* slots, int count, int n, double* norm_out, int stride_out, int off_out);
+void maus_launch_herm_pick(hipStream_t st, const c128* S, long lds_, c128* X, long ldx, const int* slots, int count, const c128* V, int n, int* idx_out, double* norm_out);
+int maus_gmres_run(maus_ctx* ctx, const int* slots, int count, const double* shift, const double* psi, int rhs_mode,
+                   const int32_t* use_jacobi, double rtol, int restart, int maxiter, int32_t* info_out, int32_t* inner_out, int32_t* status);
+int maus_jacobi_check_run(maus_ctx* ctx, int count, const double* shift, const double* psi, int32_t* ok);
+
+// ---- context ---------------------------------------------------------------------------
+struct ProfRec { int klass; hipEvent_t e0, e1; double flops, bytes; };
+
+struct maus_ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::string err;
+    c128* A = nullptr; int rows = 0, cols = 0;      // problem matrix
+    c128* b = nullptr; int bn = 0;                  // rhs
+    c128* V = nullptr; int vn = 0;                  // eigenvectors (Hermitian shortcut)
+    int cap = 0; long ldp = 0;                      // population
+    c128 *X = nullptr, *U = nullptr, *W = nullptr, *Y = nullptr;
+    // per-call scalar staging (device), sized for `scal_cap` candidates
+    int scal_cap = 0;
+    int *d_slots = nullptr, *d_i1 = nullptr, *d_i2 = nullptr;
+    c128 *d_c1 = nullptr, *d_c2 = nullptr;
+    double *d_r1 = nullptr, *d_r2 = nullptr;
+    // LU workspace
+    c128* H = nullptr; size_t Hbytes = 0; int Hg = 0; int Hnpad = 0;
+    int *ipiv = nullptr, *info = nullptr, *flags = nullptr;
+    double* Upert = nullptr; size_t Ubytes = 0;
+    // generic scratch (host-GEMM / host-LU test entry points, GMRES)
+    void* scratch = nullptr; size_t scratch_bytes = 0;
+    // measurement
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool prof_on = false;
+    std::vector<ProfRec> pending;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t cur0 = nullptr;
+    int launches[KC_COUNT] = {0}; double ms[KC_COUNT] = {0}, flops[KC_COUNT] = {0}, bytes[KC_COUNT] = {0};
+};
+
+static thread_local std::string g_err;
+
+#define FAIL(ctx, msg) do { (ctx)->err = (msg); return -1; } while (0)
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+        char buf_[512]; snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+        (ctx)->err = buf_; return -1; } } while (0)
+
+static int ensure_scalars(maus_ctx* c, int count) {
+    if (count <= c->scal_cap) return 0;
+    int cap = std::max(count, 2 * c->scal_cap);
+    cap = std::max(cap, 64);
+    void** ptrs[] = {(void**)&c->d_slots, (void**)&c->d_i1, (void**)&c->d_i2, (void**)&c->d_c1, (void**)&c->d_c2, (void**)&c->d_r1, (void**)&c->d_r2};
+    for (auto p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    HIPCHK(c, hipMalloc((void**)&c->d_slots, sizeof(int) * cap));
+    HIPCHK(c, hipMalloc((void**)&c->d_i1, sizeof(int) * cap));
+    HIPCHK(c, hipMalloc((void**)&c->d_i2, sizeof(int) * cap));
+    HIPCHK(c, hipMalloc((void**)&c->d_c1, sizeof(c128) * cap));
+    HIPCHK(c, hipMalloc((void**)&c->d_c2, sizeof(c128) * cap));
+    HIPCHK(c, hipMalloc((void**)&c->d_r1, sizeof(double) * cap * 4));
+    HIPCHK(c, hipMalloc((void**)&c->d_r2, sizeof(double) * cap * 4));
+    c->scal_cap = cap;
+    return 0;
+}
+
+static int ensure_scratch(maus_ctx* c, size_t bytes) {
+    if (bytes <= c->scratch_bytes) return 0;
+    if (c->scratch) { (void)hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    HIPCHK(c, hipMalloc(&c->scratch, bytes));
+    c->scratch_bytes = bytes;
+    return 0;
+}
+
+static int check_slots(maus_ctx* c, const int* slots, int count) {
+    if (count < 0) FAIL(c, "negative count");
+    for (int i = 0; i < count; ++i) if (slots[i] < 0 || slots[i] >= c->cap) FAIL(c, "slot out of range");
+    return 0;
+}
+
+static int upload_slots(maus_ctx* c, const int* slots, int count) {
+    if (check_slots(c, slots, count)) return -1;
+    if (ensure_scalars(c, count)) return -1;
+    HIPCHK(c, hipMemcpyAsync(c->d_slots, slots, sizeof(int) * count, hipMemcpyHostToDevice, c->st));
+    return 0;
+}
+
+// profiling hook handed to the LU driver
+static void prof_tick(void* ud, int klass, int phase, double flops, double bytes) {
+    maus_ctx* c = (maus_ctx*)ud;
+    if (!c->prof_on) return;
+    auto get = [&]() { hipEvent_t e; if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
+    if (phase == 0) { c->cur0 = get(); (void)hipEventRecord(c->cur0, c->st); }
+    else { hipEvent_t e1 = get(); (void)hipEventRecord(e1, c->st); c->pending.push_back({klass, c->cur0, e1, flops, bytes}); c->cur0 = nullptr; }
+}
+
+static void prof_resolve(maus_ctx* c) {
+    if (c->pending.empty()) return;
+    (void)hipStreamSynchronize(c->st);
+    for (auto& r : c->pending) {
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        c->launches[r.klass]++; c->ms[r.klass] += ms; c->flops[r.klass] += r.flops; c->bytes[r.klass] += r.bytes;
+        c->pool.push_back(r.e0); c->pool.push_back(r.e1);
+    }
+    c->pending.clear();
+}
+
+struct ProfScope {
+    maus_ctx* c; int k; double f, b;
+    ProfScope(maus_ctx* c_, int k_, double f_ = 0, double b_ = 0) : c(c_), k(k_), f(f_), b(b_) { prof_tick(c, k, 0, 0, 0); }
+    ~ProfScope() { prof_tick(c, k, 1, f, b); }
+};
+
+extern "C" {
+
+int maus_abi_version(void) { return 1; }
+
+int maus_ctx_create(int device, maus_ctx** out) {
+    if (!out) return -1;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_err = "no such HIP device"; return -1; }
+    if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return -1; }
+    maus_ctx* c = new maus_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { delete c; g_err = "hipStreamCreate failed"; return -1; }
+    (void)hipEventCreate(&c->t0); (void)hipEventCreate(&c->t1);
+    *out = c;
+    return 0;
+}
+
+int maus_ctx_destroy(maus_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->st);
+    void* ptrs[] = {c->A, c->b, c->V, c->X, c->U, c->W, c->Y, c->d_slots, c->d_i1, c->d_i2, c->d_c1, c->d_c2, c->d_r1, c->d_r2,
+                    c->H, c->ipiv, c->info, c->flags, c->Upert, c->scratch};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& r : c->pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    (void)hipStreamDestroy(c->st);
+    delete c;
+    return 0;
+}
+
+const char* maus_last_error(const maus_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+int maus_device_info(maus_ctx* c, char* name, int name_len, int* cus, size_t* hbm_total, size_t* hbm_free) {
+    hipDeviceProp_t p;
+    HIPCHK(c, hipGetDeviceProperties(&p, c->device));
+    if (name && name_len > 0) { snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName); }
+    if (cus) *cus = p.multiProcessorCount;
+    size_t fr = 0, tot = 0;
+    HIPCHK(c, hipMemGetInfo(&fr, &tot));
+    if (hbm_total) *hbm_total = tot;
+    if (hbm_free) *hbm_free = fr;
+    return 0;
+}
+
+int maus_sync(maus_ctx* c) { HIPCHK(c, hipStreamSynchronize(c->st)); return 0; }
+
+static void free_population(maus_ctx* c) {
+    c128** ps[] = {&c->X, &c->U, &c->W, &c->Y};
+    for (auto p : ps) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    c->cap = 0; c->ldp = 0;
+}
+
+int maus_set_matrix(maus_ctx* c, const double* a, int rows, int cols) {
+    if (!a || rows <= 0 || cols <= 0) FAIL(c, "maus_set_matrix: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (rows != c->rows || cols != c->cols) {
+        if (c->A) { (void)hipFree(c->A); c->A = nullptr; }
+        if (std::max(rows, cols) != c->ldp) free_population(c);      // vector length changed
+        if (c->V) { (void)hipFree(c->V); c->V = nullptr; c->vn = 0; }
+        HIPCHK(c, hipMalloc((void**)&c->A, sizeof(c128) * (size_t)rows * cols));
+        c->rows = rows; c->cols = cols;
+    }
+    HIPCHK(c, hipMemcpy(c->A, a, sizeof(c128) * (size_t)rows * cols, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int maus_set_rhs(maus_ctx* c, const double* b, int n) {
+    if (!b || n <= 0) FAIL(c, "maus_set_rhs: bad arguments");
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (n != c->bn) { if (c->b) (void)hipFree(c->b); c->b = nullptr; HIPCHK(c, hipMalloc((void**)&c->b, sizeof(c128) * n)); c->bn = n; }
+    HIPCHK(c, hipMemcpy(c->b, b, sizeof(c128) * n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int maus_set_eigvecs(maus_ctx* c, const double* v, int n) {
+    if (!v || n <= 0 || n != c->rows || n != c->cols) FAIL(c, "maus_set_eigvecs: n must match the square problem matrix");
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (n != c->vn) { if (c->V) (void)hipFree(c->V); c->V = nullptr; HIPCHK(c, hipMalloc((void**)&c->V, sizeof(c128) * (size_t)n * n)); c->vn = n; }
+    HIPCHK(c, hipMemcpy(c->V, v, sizeof(c128) * (size_t)n * n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int maus_pop_capacity(maus_ctx* c) { return c->cap; }
+
+int maus_pop_reserve(maus_ctx* c, int capacity) {
+    if (c->rows <= 0) FAIL(c, "maus_pop_reserve: set the matrix first");
+    if (capacity <= c->cap) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    long ld = std::max(c->rows, c->cols);
+    int newcap = std::max(capacity, c->cap + c->cap / 2);
+    c128** ps[] = {&c->X, &c->U, &c->W, &c->Y};
+    for (auto p : ps) {
+        c128* nw = nullptr;
+        HIPCHK(c, hipMalloc((void**)&nw, sizeof(c128) * (size_t)newcap * ld));
+        HIPCHK(c, hipMemset(nw, 0, sizeof(c128) * (size_t)newcap * ld));
+        if (*p) { HIPCHK(c, hipMemcpy(nw, *p, sizeof(c128) * (size_t)c->cap * ld, hipMemcpyDeviceToDevice)); (void)hipFree(*p); }
+        *p = nw;
+    }
+    c->cap = newcap; c->ldp = ld;
+    return 0;
+}
+
+static c128* pop_array(maus_ctx* c, int which) {
+    switch (which) { case MAUS_POP_X: return c->X; case MAUS_POP_U: return c->U; case MAUS_POP_W: return c->W; case MAUS_POP_Y: return c->Y; }
+    return nullptr;
+}
+
+static bool contiguous(const int* slots, int count) {
+    for (int i = 1; i < count; ++i) if (slots[i] != slots[0] + i) return false;
+    return true;
+}
+
+int maus_pop_put(maus_ctx* c, int which, const int* slots, int count, const double* host, int len) {
+    c128* P = pop_array(c, which);
+    if (!P) FAIL(c, "maus_pop_put: population not reserved / bad array id");
+    if (len <= 0 || len > c->ldp) FAIL(c, "maus_pop_put: bad vector length");
+    if (check_slots(c, slots, count)) return -1;
+    if (count == 0) return 0;
+    if (contiguous(slots, count)) {
+        HIPCHK(c, hipMemcpy2DAsync(P + (long)slots[0] * c->ldp, sizeof(c128) * c->ldp, host, sizeof(c128) * len, sizeof(c128) * len, count, hipMemcpyHostToDevice, c->st));
+    } else {
+        for (int i = 0; i < count; ++i)
+            HIPCHK(c, hipMemcpyAsync(P + (long)slots[i] * c->ldp, host + 2 * (size_t)i * len, sizeof(c128) * len, hipMemcpyHostToDevice, c->st));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
+int maus_pop_get(maus_ctx* c, int which, const int* slots, int count, double* host, int len) {
+    c128* P = pop_array(c, which);
+    if (!P) FAIL(c, "maus_pop_get: population not reserved / bad array id");
+    if (len <= 0 || len > c->ldp) FAIL(c, "maus_pop_get: bad vector length");
+    if (check_slots(c, slots, count)) return -1;
+    if (count == 0) return 0;
+    if (contiguous(slots, count)) {
+        HIPCHK(c, hipMemcpy2DAsync(host, sizeof(c128) * len, P + (long)slots[0] * c->ldp, sizeof(c128) * c->ldp, sizeof(c128) * len, count, hipMemcpyDeviceToHost, c->st));
+    } else {
+        for (int i = 0; i < count; ++i)
+            HIPCHK(c, hipMemcpyAsync(host + 2 * (size_t)i * len, P + (long)slots[i] * c->ldp, sizeof(c128) * len, hipMemcpyDeviceToHost, c->st));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
+// Y[slot] = A @ X[slot] for all listed slots:  C[count, rows] = Xg[count, cols] * A^T  (A as [n][k])
+static void matvec_into_Y(maus_ctx* c, const c128* src, int count) {
+    ProfScope ps(c, KC_GEMM, 8.0 * count * c->rows * c->cols, 16.0 * ((double)c->rows * c->cols + 2.0 * count * c->ldp));
+    maus_zgemm_launch_idx(c->st, count, c->rows, c->cols, src, c->ldp, 0, c->A, c->cols, 0, c->Y, c->ldp, 0,
+                          1.0, 0, 1, /*blay*/1, false, false, c->d_slots, c->d_slots);
+}
+
+int maus_matvec_rayleigh(maus_ctx* c, const int* slots, int count, double* num, double* den) {
+    if (!c->A || !c->X) FAIL(c, "maus_matvec_rayleigh: matrix/population missing");
+    if (c->rows != c->cols) FAIL(c, "maus_matvec_rayleigh: square matrix required");
+    if (count == 0) return 0;
+    if (upload_slots(c, slots, count)) return -1;
+    matvec_into_Y(c, c->X, count);
+    { ProfScope ps(c, KC_VEC, 0, 32.0 * count * c->rows);
+      maus_launch_rayleigh_dots(c->st, c->X, c->Y, c->ldp, c->d_slots, count, c->rows, c->d_c1, c->d_c2); }
+    HIPCHK(c, hipMemcpyAsync(num, c->d_c1, sizeof(c128) * count, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(den, c->d_c2, sizeof(c128) * count, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
+static int ensure_lu_ws(maus_ctx* c, int n, int want) {
+    int npad = round_up(n, 32);
+    if (npad > maus_lu_max_npad()) FAIL(c, "direct LU path supports n <= 4096 in this build");
+    size_t per = sizeof(c128) * (size_t)npad * (npad + 32);
+    if (c->H && c->Hnpad == npad && c->Hg >= want) return 0;
+    size_t fr = 0, tot = 0;
+    HIPCHK(c, hipMemGetInfo(&fr, &tot));
+    if (c->H) fr += c->Hbytes;
+    int gmax = (int)std::max<size_t>(1, (size_t)(fr * 0.80) / per);
+    const char* env = getenv("MAUS_LU_BATCH");
+    int cap = env ? std::max(1, atoi(env)) : 256;
+    int G = std::min(std::min(want, cap), gmax);
+    if (c->H && c->Hnpad == npad && c->Hg >= G) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (c->H) { (void)hipFree(c->H); c->H = nullptr; }
+    if (c->ipiv) { (void)hipFree(c->ipiv); c->ipiv = nullptr; }
+    if (c->info) { (void)hipFree(c->info); c->info = nullptr; }
+    if (c->flags) { (void)hipFree(c->flags); c->flags = nullptr; }
+    HIPCHK(c, hipMalloc((void**)&c->H, per * G));
+    HIPCHK(c, hipMalloc((void**)&c->ipiv, sizeof(int) * (size_t)G * npad));
+    HIPCHK(c, hipMalloc((void**)&c->info, sizeof(int) * G));
+    HIPCHK(c, hipMalloc((void**)&c->flags, sizeof(int) * G));
+    c->Hbytes = per * G; c->Hg = G; c->Hnpad = npad;
+    return 0;
+}
+
+static LuWs make_ws(maus_ctx* c, int n, int G) {
+    LuWs w;
+    w.n = n; w.npad = c->Hnpad; w.ldh = w.npad + 32; w.strideH = (long)w.npad * w.ldh; w.G = G;
+    w.H = c->H; w.ipiv = c->ipiv; w.info = c->info; w.flags = c->flags; w.st = c->st;
+    w.tick = prof_tick; w.ud = c;
+    return w;
+}
+
+static int lu_nbo() { const char* e = getenv("MAUS_LU_NBO"); int v = e ? atoi(e) : 256; if (v < 32) v = 32; return (v / 32) * 32; }
+
+static void finish_status(int G, const int* info, const int* flags, int32_t* status) {
+    for (int g = 0; g < G; ++g) {
+        if (flags[g] & 1) status[g] = -1;
+        else if (info[g] > 0) status[g] = info[g];
+        else if (flags[g] & 2) status[g] = -2;
+        else status[g] = 0;
+    }
+}
+
+int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double* shift, const double* psi,
+                          int rhs_mode, int pert_mode, const void* pert_data, int32_t* status) {
+    if (!c->A || !c->X) FAIL(c, "maus_shifted_lu_solve: matrix/population missing");
+    if (c->rows != c->cols) FAIL(c, "maus_shifted_lu_solve: square matrix required");
+    if (rhs_mode == 1 && (!c->b || c->bn != c->rows)) FAIL(c, "maus_shifted_lu_solve: rhs b not set");
+    if (pert_mode == MAUS_PERT_MT19937) FAIL(c, "MAUS_PERT_MT19937 not available in this build");
+    if (pert_mode == MAUS_PERT_UNIFORM && !pert_data) FAIL(c, "pert_data missing");
+    if (count == 0) return 0;
+    const int n = c->rows;
+    if (check_slots(c, slots, count)) return -1;
+    if (ensure_scalars(c, count)) return -1;
+    if (ensure_lu_ws(c, n, count)) return -1;
+    const int Gmax = c->Hg;
+    std::vector<int> h_info(Gmax), h_flags(Gmax);
+    for (int off = 0; off < count; off += Gmax) {
+        const int G = std::min(Gmax, count - off);
+        LuWs w = make_ws(c, n, G);
+        HIPCHK(c, hipMemcpyAsync(c->d_slots, slots + off, sizeof(int) * G, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(c->d_c1, shift + 2 * (size_t)off, sizeof(c128) * G, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(c->d_r1, psi + off, sizeof(double) * G, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemsetAsync(c->info, 0, sizeof(int) * G, c->st));
+        HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int) * G, c->st));
+        const double* dU = nullptr;
+        if (pert_mode == MAUS_PERT_UNIFORM) {
+            size_t ub = sizeof(double) * 2 * (size_t)n * n * G;
+            if (ub > c->Ubytes) { if (c->Upert) (void)hipFree(c->Upert); c->Upert = nullptr; HIPCHK(c, hipMalloc((void**)&c->Upert, ub)); c->Ubytes = ub; }
+            HIPCHK(c, hipMemcpyAsync(c->Upert, (const double*)pert_data + 2 * (size_t)n * n * off, ub, hipMemcpyHostToDevice, c->st));
+            dU = c->Upert;
+        }
+        maus_build_h(w, c->A, c->d_c1, c->d_r1, rhs_mode, c->X, c->ldp, c->d_slots, c->b, pert_mode, dU);
+        maus_lu_factor(w, lu_nbo());
+        maus_lu_backsolve(w, c->W, c->ldp, c->d_slots, nullptr);
+        HIPCHK(c, hipMemcpyAsync(h_info.data(), c->info, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(h_flags.data(), c->flags, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        HIPCHK(c, hipGetLastError());
+        finish_status(G, h_info.data(), h_flags.data(), status + off);
+    }
+    return 0;
+}
+
+int maus_lu_solve_host(maus_ctx* c, int count, int n, const double* a, const double* b, double* x, int32_t* status, int32_t* ipiv_out) {
+    if (count <= 0 || n <= 0) FAIL(c, "maus_lu_solve_host: bad sizes");
+    if (ensure_lu_ws(c, n, count)) return -1;
+    const int Gmax = c->Hg;
+    size_t ab = sizeof(c128) * (size_t)n * n, bb = sizeof(c128) * (size_t)n;
+    if (ensure_scratch(c, (ab + 2 * bb) * Gmax)) return -1;
+    c128* dA = (c128*)c->scratch; c128* dB = dA + (size_t)n * n * Gmax; c128* dX = dB + (size_t)n * Gmax;
+    std::vector<int> h_info(Gmax), h_flags(Gmax);
+    for (int off = 0; off < count; off += Gmax) {
+        const int G = std::min(Gmax, count - off);
+        LuWs w = make_ws(c, n, G);
+        HIPCHK(c, hipMemcpyAsync(dA, a + 2 * (size_t)n * n * off, ab * G, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(dB, b + 2 * (size_t)n * off, bb * G, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemsetAsync(c->info, 0, sizeof(int) * G, c->st));
+        HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int) * G, c->st));
+        maus_load_h(w, dA, dB);
+        maus_lu_factor(w, lu_nbo());
+        maus_lu_backsolve(w, nullptr, 0, nullptr, dX);
+        HIPCHK(c, hipMemcpyAsync(x + 2 * (size_t)n * off, dX, bb * G, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(h_info.data(), c->info, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(h_flags.data(), c->flags, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
+        if (ipiv_out) {
+            // ipiv rows are npad long on the device; return the first n of each
+            HIPCHK(c, hipMemcpy2DAsync(ipiv_out + (size_t)off * n, sizeof(int) * n, c->ipiv, sizeof(int) * c->Hnpad, sizeof(int) * n, G, hipMemcpyDeviceToHost, c->st));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        HIPCHK(c, hipGetLastError());
+        finish_status(G, h_info.data(), h_flags.data(), status + off);
+    }
+    return 0;
+}
+
+int maus_relax_normalise(maus_ctx* c, const int* slots, int count, const double* alpha, int normalise, double* norm_out) {
+    if (!c->X) FAIL(c, "maus_relax_normalise: population missing");
+    if (count == 0) return 0;
+    if (upload_slots(c, slots, count)) return -1;
+    const int n = c->rows;
+    HIPCHK(c, hipMemcpyAsync(c->d_c1, alpha, sizeof(c128) * count, hipMemcpyHostToDevice, c->st));
+    { ProfScope ps(c, KC_VEC, 0, 48.0 * count * n);
+      maus_launch_relax(c->st, c->X, c->W, c->ldp, c->d_slots, count, n, c->d_c1, normalise, c->d_r1); }
+    HIPCHK(c, hipMemcpyAsync(norm_out, c->d_r1, sizeof(double) * count, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
+int maus_residual(maus_ctx* c, int kind, const int* slots, int count, const double* lam, double* resid, int32_t* finite) {
+    if (!c->A || !c->X) FAIL(c, "maus_residual: matrix/population missing");
+    if (count == 0) return 0;
+    if (upload_slots(c, slots, count)) return -1;
+    if (kind == MAUS_EIG || kind == MAUS_LINEAR) {
+        if (c->rows != c->cols) FAIL(c, "maus_residual: square matrix required");
+        if (kind == MAUS_LINEAR && (!c->b || c->bn != c->rows)) FAIL(c, "maus_residual: rhs b not set");
+        if (kind == MAUS_EIG && !lam) FAIL(c, "maus_residual: lambda missing");
+        if (lam) HIPCHK(c, hipMemcpyAsync(c->d_c1, lam, sizeof(c128) * count, hipMemcpyHostToDevice, c->st));
+        matvec_into_Y(c, c->X, count);
+        { ProfScope ps(c, KC_VEC, 0, 32.0 * count * c->rows);
+          maus_launch_residual(c->st, kind, c->X, c->Y, c->ldp, c->d_slots, count, c->rows, lam ? c->d_c1 : nullptr, c->b, c->d_r1, c->d_i1); }
+    } else if (kind == MAUS_SVD) {
+        if (!lam) FAIL(c, "maus_residual: sigma missing");
+        HIPCHK(c, hipMemcpyAsync(c->d_c1, lam, sizeof(c128) * count, hipMemcpyHostToDevice, c->st));
+        // ||A v - s u||  : Y = X * A^T  (count x rows)
+        matvec_into_Y(c, c->X, count);
+        maus_launch_svd_resid(c->st, c->Y, c->U, c->ldp, c->d_slots, count, c->rows, c->d_c1, c->d_r1, 0, c->d_i1);
+        // ||A^H u - s v||: W = U * conj(A)  (count x cols), B = conj(A) as [k=rows][n=cols]
+        { ProfScope ps(c, KC_GEMM, 8.0 * count * c->rows * c->cols, 16.0 * (double)c->rows * c->cols);
+          maus_zgemm_launch_idx(c->st, count, c->cols, c->rows, c->U, c->ldp, 0, c->A, c->cols, 0, c->W, c->ldp, 0,
+                                1.0, 0, 1, 0, false, true, c->d_slots, c->d_slots); }
+        maus_launch_svd_resid(c->st, c->W, c->X, c->ldp, c->d_slots, count, c->cols, c->d_c1, c->d_r1, 1, c->d_i1);
+    } else FAIL(c, "maus_residual: unknown kind");
+    HIPCHK(c, hipMemcpyAsync(resid, c->d_r1, sizeof(double) * count, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(finite, c->d_i1, sizeof(int) * count, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
+int maus_svd_power_step(maus_ctx* c, const int* slots, int count, double* norms_out) {
+    if (!c->A || !c->X) FAIL(c, "maus_svd_power_step: matrix/population missing");
+    if (count == 0) return 0;
+    if (upload_slots(c, slots, count)) return -1;
+    // ||v_in||
+    maus_launch_norm(c->st, c->X, c->ldp, c->d_slots, count, c->cols, c->d_r1, 4, 0);
+    // t = A v -> Y ; sigma1 = ||t|| ; u = t / (sigma1 > 1e-10 ? sigma1 : 1)
+    matvec_into_Y(c, c->X, count);
+    maus_launch_norm_scale(c->st, c->Y, c->U, c->ldp, c->d_slots, count, c->rows, c->d_r1, 4, 1);
+    maus_launch_norm(c->st, c->U, c->ldp, c->d_slots, count, c->rows, c->d_r1, 4, 2);
+    // s = A^H u -> W ; sigma2 = ||s|| ; v = s / (sigma2 > 1e-10 ? sigma2 : 1)
+    { ProfScope ps(c, KC_GEMM, 8.0 * count * c->rows * c->cols, 16.0 * (double)c->rows * c->cols);
+      maus_zgemm_launch_idx(c->st, count, c->cols, c->rows, c->U, c->ldp, 0, c->A, c->cols, 0, c->W, c->ldp, 0,
+                            1.0, 0, 1, 0, false, true, c->d_slots, c->d_slots); }
+    maus_launch_norm_scale(c->st, c->W, c->X, c->ldp, c->d_slots, count, c->cols, c->d_r1, 4, 3);
+    HIPCHK(c, hipMemcpyAsync(norms_out, c->d_r1, sizeof(double) * 4 * count, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
+int maus_herm_match(maus_ctx* c, const int* slots, int count, int32_t* idx_out, double* norm_out) {
+    if (!c->V || !c->X) FAIL(c, "maus_herm_match: eigenvectors/population missing");
+    if (count == 0) return 0;
+    if (upload_slots(c, slots, count)) return -1;
+    const int n = c->rows;
+    // scores: Y[slot][j] = sum_i conj(X[slot][i]) V[i][j]
+    { ProfScope ps(c, KC_GEMM, 8.0 * count * n * n, 16.0 * (double)n * n);
+      maus_zgemm_launch_idx(c->st, count, n, n, c->X, c->ldp, 0, c->V, n, 0, c->Y, c->ldp, 0, 1.0, 0, 1, 0, true, false, c->d_slots, c->d_slots); }
+    maus_launch_herm_pick(c->st, c->Y, c->ldp, c->X, c->ldp, c->d_slots, count, c->V, n, c->d_i1, c->d_r1);
+    HIPCHK(c, hipMemcpyAsync(idx_out, c->d_i1, sizeof(int) * count, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(norm_out, c->d_r1, sizeof(double) * count, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
+int maus_gmres(maus_ctx* c, const int* slots, int count, const double* shift, const double* psi, int rhs_mode,
+               const int32_t* use_jacobi, double rtol, int restart, int maxiter, int32_t* info_out, int32_t* inner_out, int32_t* status) {
+    return maus_gmres_run(c, slots, count, shift, psi, rhs_mode, use_jacobi, rtol, restart, maxiter, info_out, inner_out, status);
+}
+
+int maus_jacobi_check(maus_ctx* c, int count, const double* shift, const double* psi, int32_t* ok) {
+    return maus_jacobi_check_run(c, count, shift, psi, ok);
+}
+
+int maus_zgemm_host(maus_ctx* c, int M, int N, int K, const double* A, const double* B, double* C, int b_layout, int conj_a, int conj_b, double alpha, int beta) {
+    if (M <= 0 || N <= 0 || K <= 0) FAIL(c, "maus_zgemm_host: bad sizes");
+    size_t ea = (size_t)M * K, eb = (size_t)K * N, ec = (size_t)M * N;
+    if (ensure_scratch(c, sizeof(c128) * (ea + eb + ec))) return -1;
+    c128* dA = (c128*)c->scratch; c128* dB = dA + ea; c128* dC = dB + eb;
+    HIPCHK(c, hipMemcpyAsync(dA, A, sizeof(c128) * ea, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(dB, B, sizeof(c128) * eb, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(dC, C, sizeof(c128) * ec, hipMemcpyHostToDevice, c->st));
+    { ProfScope ps(c, KC_GEMM, 8.0 * M * N * K, 16.0 * (ea + eb + 2.0 * ec));
+      maus_zgemm_launch_idx(c->st, M, N, K, dA, K, 0, dB, b_layout ? K : N, 0, dC, N, 0, alpha, beta, 1, b_layout, conj_a != 0, conj_b != 0, nullptr, nullptr); }
+    HIPCHK(c, hipMemcpyAsync(C, dC, sizeof(c128) * ec, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int maus_timer_start(maus_ctx* c) { HIPCHK(c, hipEventRecord(c->t0, c->st)); return 0; }
+int maus_timer_stop(maus_ctx* c, float* ms) {
+    HIPCHK(c, hipEventRecord(c->t1, c->st));
+    HIPCHK(c, hipEventSynchronize(c->t1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->t0, c->t1));
+    return 0;
+}
+
+int maus_profile_enable(maus_ctx* c, int on) {
+    prof_resolve(c);
+    c->prof_on = on != 0;
+    if (on) for (int k = 0; k < KC_COUNT; ++k) { c->launches[k] = 0; c->ms[k] = 0; c->flops[k] = 0; c->bytes[k] = 0; }
+    return 0;
+}
+
+int maus_profile_read(maus_ctx* c, int klass, int* launches, double* total_ms, double* flops, double* bytes) {
+    if (klass < 0 || klass >= KC_COUNT) FAIL(c, "maus_profile_read: bad class");
+    prof_resolve(c);
+    if (launches) *launches = c->launches[klass];
+    if (total_ms) *total_ms = c->ms[klass];
+    if (flops) *flops = c->flops[klass];
+    if (bytes) *bytes = c->bytes[klass];
+    return 0;
+}
+
+}  // extern "C"
+
+// accessors for the GMRES translation unit
+hipStream_t maus_ctx_stream(maus_ctx* c) { return c->st; }
+void maus_ctx_set_error(maus_ctx* c, const char* m) { c->err = m; }

@@ -1,0 +1,64 @@
+// Shared device/host helpers for libmaus_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double2 c128;                                   // interleaved (re, im) = NumPy complex128
+typedef double d4 __attribute__((ext_vector_type(4)));  // one v_mfma_f64_16x16x4 accumulator
+
+#define MAUS_WAVE 64
+
+__device__ __forceinline__ c128 cmake(double r, double i) { c128 z; z.x = r; z.y = i; return z; }
+__device__ __forceinline__ c128 cadd(c128 a, c128 b) { return cmake(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ c128 csub(c128 a, c128 b) { return cmake(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ c128 cmul(c128 a, c128 b) { return cmake(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ c128 cconj(c128 a) { return cmake(a.x, -a.y); }
+// a -= b*c
+__device__ __forceinline__ void cfms(c128& a, c128 b, c128 c) {
+    a.x = fma(-b.x, c.x, a.x); a.x = fma(b.y, c.y, a.x);
+    a.y = fma(-b.x, c.y, a.y); a.y = fma(-b.y, c.x, a.y);
+}
+// a += b*c
+__device__ __forceinline__ void cfma(c128& a, c128 b, c128 c) {
+    a.x = fma(b.x, c.x, a.x); a.x = fma(-b.y, c.y, a.x);
+    a.y = fma(b.x, c.y, a.y); a.y = fma(b.y, c.x, a.y);
+}
+// a += conj(b)*c
+__device__ __forceinline__ void cfma_conj(c128& a, c128 b, c128 c) {
+    a.x = fma(b.x, c.x, a.x); a.x = fma(b.y, c.y, a.x);
+    a.y = fma(b.x, c.y, a.y); a.y = fma(-b.y, c.x, a.y);
+}
+// LAPACK dcabs1: |re| + |im|  (izamax pivot rule)
+__device__ __forceinline__ double cabs1(c128 a) { return fabs(a.x) + fabs(a.y); }
+// 1/z by Smith's algorithm (no intermediate overflow for representable results)
+__device__ __forceinline__ c128 crecip(c128 z) {
+    if (fabs(z.x) >= fabs(z.y)) {
+        double t = z.y / z.x, d = z.x + z.y * t;
+        return cmake(1.0 / d, -t / d);
+    } else {
+        double t = z.x / z.y, d = z.x * t + z.y;
+        return cmake(t / d, -1.0 / d);
+    }
+}
+// a / b by Smith's algorithm
+__device__ __forceinline__ c128 cdiv(c128 a, c128 b) {
+    if (fabs(b.x) >= fabs(b.y)) {
+        double t = b.y / b.x, d = b.x + b.y * t;
+        return cmake((a.x + a.y * t) / d, (a.y - a.x * t) / d);
+    } else {
+        double t = b.x / b.y, d = b.x * t + b.y;
+        return cmake((a.x * t + a.y) / d, (a.y * t - a.x) / d);
+    }
+}
+__device__ __forceinline__ bool cfinite(c128 a) { return isfinite(a.x) && isfinite(a.y); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// kernel classes for the profiling counters (maus_profile_read)
+enum { KC_GEMM = 0, KC_PANEL = 1, KC_TRSM = 2, KC_LASWP = 3, KC_BUILD = 4, KC_BACKSOLVE = 5, KC_VEC = 6, KC_COUNT = 7 };

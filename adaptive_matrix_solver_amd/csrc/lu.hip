@@ -1,0 +1,488 @@
+// Batched Psi-regularised shifted LU solve for the MAUS candidate step (gfx950).
+//
+// Replaces, per candidate k (AMS = the reference file):
+//   A_t   = A - lambda_k * eye(N)                               AMS:270
+//   reg   = psi_k * eye(N) + 0.15*psi_k*((U1-.5) + i(U2-.5))    AMS:49-50
+//   H     = A_t + reg                                           AMS:52
+//   w     = scipy.linalg.solve(H, rhs)  (zgetrf + zgetrs)       AMS:59
+//
+// Design (one workspace of G matrices, all kernels batched over G):
+//   * H is row-major [npad][ldh], npad = roundup(n,32), ldh = npad + 32.  The pad block is the
+//     identity (never pivoted into), and column `npad` carries the right-hand side, so the
+//     forward substitution L y = P b happens inside the factorisation and only U x = y remains.
+//   * right-looking outer blocks of NBO columns; each block column is factored by a host-driven
+//     recursion (halving down to 32-wide panels) so that every flop outside the 32-wide base
+//     panels is a call of the MFMA zgemm; row swaps are applied inside the block window by the
+//     recursion and, to the right of it, once per outer block (the L part to the left is never
+//     needed again because y is carried in the augmented column).
+//   * base panel: one workgroup per matrix, rows owned by threads, 4-column sub-blocks kept in
+//     registers; pivot rule = LAPACK izamax (max |re|+|im|, first index wins).
+#include "common.h"
+#include <climits>
+
+void maus_zgemm_launch(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,
+                       const c128* B, long ldb, long sB, c128* C, long ldc, long sC,
+                       double alpha, int beta, int batch, int blay, bool conja, bool conjb);
+
+namespace {
+
+constexpr int NBP = 32;     // base panel width
+constexpr int PW = 4;       // register sub-block width inside the panel
+constexpr int PT = 512;     // panel threads (8 waves, 2 per SIMD -> 256 VGPR budget)
+
+// ---------------------------------------------------------------------------------------
+// H build.  grid = (npad, G), block = 256.  pert_mode 0: none, 1: uniform draws supplied.
+// Rounding order mirrors NumPy exactly: (a - lam*delta) + (psi*delta + ((u-.5)*psi)*0.15).
+// flags[g] bit0 <- any non-finite entry of H or rhs (scipy's check_finite -> ValueError).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+build_h_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long strideH, c128* __restrict__ Hg,
+               const c128* __restrict__ shift, const double* __restrict__ psi,
+               int rhs_mode, const c128* __restrict__ X, long ldx, const int* __restrict__ slots,
+               const c128* __restrict__ bvec,
+               int pert_mode, const double* __restrict__ U /* [G][2][n][n] */,
+               int* __restrict__ flags)
+{
+    const int i = blockIdx.x, g = blockIdx.y;
+    c128* Hrow = Hg + (long)g * strideH + (long)i * ldh;
+    const c128 lam = shift[g];
+    const double ps = psi[g];
+    bool bad = false;
+    if (i < n) {
+        const c128* Arow = A + (long)i * n;
+        const double* U1 = (pert_mode == 1) ? U + ((long)g * 2 + 0) * n * n + (long)i * n : nullptr;
+        const double* U2 = (pert_mode == 1) ? U + ((long)g * 2 + 1) * n * n + (long)i * n : nullptr;
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            c128 a = Arow[j];
+            double pr = 0.0, pi = 0.0;
+            if (pert_mode == 1) {
+                pr = __dmul_rn(__dmul_rn(__dsub_rn(U1[j], 0.5), ps), 0.15);
+                pi = __dmul_rn(__dmul_rn(__dsub_rn(U2[j], 0.5), ps), 0.15);
+            }
+            c128 h;
+            if (j == i) {
+                h.x = __dadd_rn(__dsub_rn(a.x, lam.x), __dadd_rn(ps, pr));
+                h.y = __dadd_rn(__dsub_rn(a.y, lam.y), __dadd_rn(0.0, pi));
+            } else {
+                h.x = __dadd_rn(a.x, pr);
+                h.y = __dadd_rn(a.y, pi);
+            }
+            bad |= !cfinite(h);
+            Hrow[j] = h;
+        }
+        for (int j = n + threadIdx.x; j < npad; j += blockDim.x) Hrow[j] = cmake(0.0, 0.0);
+    } else {
+        for (int j = threadIdx.x; j < npad; j += blockDim.x) Hrow[j] = cmake(j == i ? 1.0 : 0.0, 0.0);
+    }
+    // augmented block: column npad = rhs, the other 31 columns zero
+    for (int j = threadIdx.x; j < NBP; j += blockDim.x) {
+        c128 v = cmake(0.0, 0.0);
+        if (j == 0 && i < n) {
+            v = (rhs_mode == 0) ? X[(long)slots[g] * ldx + i] : bvec[i];
+            bad |= !cfinite(v);
+        }
+        Hrow[npad + j] = v;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[g], 1);
+}
+
+// host-provided dense matrices (maus_lu_solve_host): H <- [A_g | b_g], padded
+__global__ void __launch_bounds__(256)
+load_h_kernel(const c128* __restrict__ Ain /*[G][n][n]*/, const c128* __restrict__ bin /*[G][n]*/, int n, int npad,
+              long ldh, long strideH, c128* __restrict__ Hg, int* __restrict__ flags)
+{
+    const int i = blockIdx.x, g = blockIdx.y;
+    c128* Hrow = Hg + (long)g * strideH + (long)i * ldh;
+    bool bad = false;
+    for (int j = threadIdx.x; j < npad; j += blockDim.x) {
+        c128 v = cmake((i == j && i >= n) ? 1.0 : 0.0, 0.0);
+        if (i < n && j < n) { v = Ain[((long)g * n + i) * n + j]; bad |= !cfinite(v); }
+        Hrow[j] = v;
+    }
+    for (int j = threadIdx.x; j < NBP; j += blockDim.x) {
+        c128 v = cmake(0.0, 0.0);
+        if (j == 0 && i < n) { v = bin[(long)g * n + i]; bad |= !cfinite(v); }
+        Hrow[npad + j] = v;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[g], 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// Base panel: LU with partial pivoting of the m x 32 block at (j0, j0), m = npad - j0.
+// One workgroup (512 threads) per matrix; thread t owns rows t, t+512, ... (RPT of them).
+// Right-looking over 4-column sub-blocks held in registers.
+// ---------------------------------------------------------------------------------------
+template <int RPT>
+__global__ void __launch_bounds__(PT)
+lu_panel_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
+                int* __restrict__ ipiv_g, int npad, int* __restrict__ info_g)
+{
+    c128* P = Hg + (long)blockIdx.x * strideH + (long)j0 * ld + j0;
+    int* ipiv = ipiv_g + (long)blockIdx.x * npad + j0;
+
+    __shared__ c128 s_piv[PW];
+    __shared__ c128 s_old[PW];
+    __shared__ double s_val[PT / 64];
+    __shared__ int s_idx[PT / 64];
+    __shared__ c128 s_L[PW][PW];
+    __shared__ c128 s_U[PW][NBP];
+    __shared__ int s_info;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_info = 0;
+    c128 R[RPT][PW];
+
+    for (int sb = 0; sb < NBP / PW; ++sb) {
+        const int c0 = sb * PW;
+        // (a) load this thread's rows of the sub-block
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = tid + k * PT;
+            if (r < m) {
+#pragma unroll
+                for (int c = 0; c < PW; ++c) R[k][c] = P[(long)r * ld + c0 + c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < PW; ++c) {
+            const int a = c0 + c;            // pivot position (panel-local row == column index)
+            // ---- pivot search: max |re|+|im| over rows >= a, first index wins ----
+            double best = -1.0; int bidx = INT_MAX;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = tid + k * PT;
+                if (r < m && r >= a) {
+                    double v = cabs1(R[k][c]);
+                    if (v > best) { best = v; bidx = r; }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                double ov = __shfl_xor(best, o, 64);
+                int oi = __shfl_xor(bidx, o, 64);
+                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            }
+            if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
+            __syncthreads();
+            best = s_val[0]; bidx = s_idx[0];
+#pragma unroll
+            for (int w = 1; w < PT / 64; ++w) {
+                double ov = s_val[w]; int oi = s_idx[w];
+                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            }
+            const int p = (bidx == INT_MAX) ? a : bidx;   // all-NaN column: no swap (input flagged non-finite)
+            // ---- publish pivot row / displaced row of the register sub-block ----
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = tid + k * PT;
+                if (r == p) {
+#pragma unroll
+                    for (int cc = 0; cc < PW; ++cc) s_piv[cc] = R[k][cc];
+                }
+                if (r == a && p != a) {
+#pragma unroll
+                    for (int cc = 0; cc < PW; ++cc) s_old[cc] = R[k][cc];
+                }
+            }
+            // the other 28 panel columns are swapped in memory
+            if (p != a && tid < NBP && (tid < c0 || tid >= c0 + PW)) {
+                c128 x = P[(long)a * ld + tid], y = P[(long)p * ld + tid];
+                P[(long)a * ld + tid] = y; P[(long)p * ld + tid] = x;
+            }
+            if (tid == 0) ipiv[a] = j0 + p;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = tid + k * PT;
+                if (p != a) {
+                    if (r == a) {
+#pragma unroll
+                        for (int cc = 0; cc < PW; ++cc) R[k][cc] = s_piv[cc];
+                    } else if (r == p) {
+#pragma unroll
+                        for (int cc = 0; cc < PW; ++cc) R[k][cc] = s_old[cc];
+                    }
+                }
+            }
+            const c128 pv = s_piv[c];
+            const bool zero_piv = (pv.x == 0.0 && pv.y == 0.0);
+            if (zero_piv && tid == 0 && s_info == 0) s_info = j0 + a + 1;   // LAPACK info (1-based)
+            const c128 rinv = zero_piv ? cmake(1.0, 0.0) : crecip(pv);
+            c128 prow[PW];
+#pragma unroll
+            for (int cc = 0; cc < PW; ++cc) prow[cc] = s_piv[cc];
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = tid + k * PT;
+                if (r < m && r > a) {
+                    c128 l = cmul(R[k][c], rinv);
+                    R[k][c] = l;
+#pragma unroll
+                    for (int cc = c + 1; cc < PW; ++cc) cfms(R[k][cc], l, prow[cc]);
+                }
+            }
+            __syncthreads();   // s_piv / s_val are rewritten by the next column
+        }
+        // (c) store the factored sub-block; rows c0..c0+3 also go to LDS (L11 of the sub-block)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = tid + k * PT;
+            if (r < m) {
+#pragma unroll
+                for (int c = 0; c < PW; ++c) P[(long)r * ld + c0 + c] = R[k][c];
+                if (r >= c0 && r < c0 + PW) {
+#pragma unroll
+                    for (int c = 0; c < PW; ++c) s_L[r - c0][c] = R[k][c];
+                }
+            }
+        }
+        __syncthreads();
+        const int nt = NBP - c0 - PW;     // trailing panel columns
+        if (nt > 0) {
+            // (d) U12 = L11^-1 * A12 for the 4 pivot rows (unit lower), one lane per column
+            if (tid < nt) {
+                const int cc = c0 + PW + tid;
+                c128 u[PW];
+#pragma unroll
+                for (int i = 0; i < PW; ++i) u[i] = P[(long)(c0 + i) * ld + cc];
+#pragma unroll
+                for (int i = 1; i < PW; ++i)
+#pragma unroll
+                    for (int q = 0; q < i; ++q) cfms(u[i], s_L[i][q], u[q]);
+#pragma unroll
+                for (int i = 0; i < PW; ++i) { P[(long)(c0 + i) * ld + cc] = u[i]; s_U[i][tid] = u[i]; }
+            }
+            __syncthreads();
+            // (e) rank-4 update of the trailing panel columns for rows below the sub-block
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = tid + k * PT;
+                if (r < m && r >= c0 + PW) {
+                    c128* row = P + (long)r * ld + c0 + PW;
+                    for (int cc = 0; cc < nt; cc += 4) {
+                        c128 x0 = row[cc], x1 = row[cc + 1], x2 = row[cc + 2], x3 = row[cc + 3];
+#pragma unroll
+                        for (int q = 0; q < PW; ++q) {
+                            const c128 l = R[k][q];
+                            cfms(x0, l, s_U[q][cc]); cfms(x1, l, s_U[q][cc + 1]);
+                            cfms(x2, l, s_U[q][cc + 2]); cfms(x3, l, s_U[q][cc + 3]);
+                        }
+                        row[cc] = x0; row[cc + 1] = x1; row[cc + 2] = x2; row[cc + 3] = x3;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0 && s_info != 0 && info_g[blockIdx.x] == 0) info_g[blockIdx.x] = s_info;
+}
+
+// ---------------------------------------------------------------------------------------
+// Row interchanges ipiv[k1..k2) applied to columns [c_lo, c_hi); one thread per column.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+laswp_kernel(c128* __restrict__ Hg, long ld, long strideH, const int* __restrict__ ipiv_g, int npad,
+             int k1, int k2, int c_lo, int c_hi)
+{
+    const int col = c_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c_hi) return;
+    c128* H = Hg + (long)blockIdx.y * strideH + col;
+    const int* ipiv = ipiv_g + (long)blockIdx.y * npad;
+    for (int k = k1; k < k2; ++k) {
+        const int p = ipiv[k];
+        if (p != k) {
+            c128 x = H[(long)k * ld], y = H[(long)p * ld];
+            H[(long)k * ld] = y; H[(long)p * ld] = x;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// B <- L11^-1 B with L11 the 32x32 unit-lower block at (j, j), B = rows j..j+32, cols [c_lo,c_hi).
+// One thread per column, L11 broadcast from LDS.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+trsm32_kernel(c128* __restrict__ Hg, long ld, long strideH, int j, int c_lo, int c_hi)
+{
+    __shared__ c128 sL[NBP][NBP + 1];
+    c128* H = Hg + (long)blockIdx.y * strideH;
+    for (int e = threadIdx.x; e < NBP * NBP; e += blockDim.x) {
+        int r = e / NBP, c = e % NBP;
+        sL[r][c] = H[(long)(j + r) * ld + j + c];
+    }
+    __syncthreads();
+    const int col = c_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c_hi) return;
+    c128 x[NBP];
+#pragma unroll
+    for (int i = 0; i < NBP; ++i) x[i] = H[(long)(j + i) * ld + col];
+#pragma unroll
+    for (int i = 1; i < NBP; ++i)
+#pragma unroll
+        for (int q = 0; q < i; ++q) cfms(x[i], sL[i][q], x[q]);
+#pragma unroll
+    for (int i = 1; i < NBP; ++i) H[(long)(j + i) * ld + col] = x[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// Back substitution U x = y (y = augmented column npad).  One workgroup per matrix,
+// 32-row blocks from the bottom: dot products of the U row tails against x (LDS), then a
+// 32x32 triangle solved by one wave.  Writes x[0..n) to W[slot]; flags bit1 <- non-finite x.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+backsolve_kernel(const c128* __restrict__ Hg, long ld, long strideH, int n, int npad,
+                 c128* __restrict__ Wg, long ldw, const int* __restrict__ slots, c128* __restrict__ xout_dense,
+                 int* __restrict__ flags)
+{
+    extern __shared__ c128 sx[];          // npad entries of x, then a 32x33 diagonal block, then 32 rhs
+    c128* sD = sx + npad;
+    c128* sR = sD + NBP * (NBP + 1);
+    const int g = blockIdx.x;
+    const c128* H = Hg + (long)g * strideH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bool bad = false;
+    for (int i0 = npad - NBP; i0 >= 0; i0 -= NBP) {
+        const int jt = i0 + NBP;          // tail starts here
+        // rhs_i = y_i - U[i, jt:] . x[jt:]  ; 4 waves x 8 rows
+        for (int rr = 0; rr < NBP / 4; ++rr) {
+            const int i = i0 + wave * (NBP / 4) + rr;
+            const c128* row = H + (long)i * ld;
+            double sr = 0.0, si = 0.0;
+            for (int j = jt + lane; j < npad; j += 64) {
+                const c128 u = row[j], xv = sx[j];
+                sr = fma(u.x, xv.x, sr); sr = fma(-u.y, xv.y, sr);
+                si = fma(u.x, xv.y, si); si = fma(u.y, xv.x, si);
+            }
+            sr = wave_sum(sr); si = wave_sum(si);
+            if (lane == 0) { const c128 y = row[npad]; sR[i - i0] = cmake(y.x - sr, y.y - si); }
+        }
+        for (int e = tid; e < NBP * NBP; e += blockDim.x) {
+            int r = e / NBP, c = e % NBP;
+            sD[r * (NBP + 1) + c] = H[(long)(i0 + r) * ld + i0 + c];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            c128 rv = (lane < NBP) ? sR[lane] : cmake(0.0, 0.0);
+            for (int j = NBP - 1; j >= 0; --j) {
+                c128 xj = cdiv(rv, sD[j * (NBP + 1) + j]);        // meaningful on lane j only
+                xj.x = __shfl(xj.x, j, 64); xj.y = __shfl(xj.y, j, 64);
+                if (lane == j) sx[i0 + j] = xj;
+                if (lane < j) cfms(rv, sD[lane * (NBP + 1) + j], xj);
+            }
+        }
+        __syncthreads();
+    }
+    c128* out = (Wg != nullptr) ? Wg + (long)slots[g] * ldw : xout_dense + (long)g * n;
+    for (int i = tid; i < n; i += blockDim.x) { c128 v = sx[i]; bad |= !cfinite(v); out[i] = v; }
+    if (__any(bad) && lane == 0) atomicOr(&flags[g], 2);
+}
+
+}  // namespace
+
+// =======================================================================================
+// host-side drivers (device pointers, all batched over G matrices on stream st)
+// =======================================================================================
+struct LuWs {
+    c128* H; long ldh; long strideH; int n; int npad; int G;
+    int* ipiv; int* info; int* flags;
+    hipStream_t st;
+    void (*tick)(void* ud, int klass, int phase, double flops, double bytes); void* ud;   // profiling hooks (may be null)
+};
+
+static inline void prof(const LuWs& w, int klass, int phase, double flops = 0, double bytes = 0) { if (w.tick) w.tick(w.ud, klass, phase, flops, bytes); }
+
+static void lu_gemm(const LuWs& w, int r0, int r1, int c0, int c1, int k0, int k1) {
+    // H[r0:r1, c0:c1] -= H[r0:r1, k0:k1] * H[k0:k1, c0:c1]
+    int M = r1 - r0, N = c1 - c0, K = k1 - k0;
+    if (M <= 0 || N <= 0 || K <= 0) return;
+    prof(w, KC_GEMM, 0);
+    maus_zgemm_launch(w.st, M, N, K, w.H + (long)r0 * w.ldh + k0, w.ldh, w.strideH,
+                      w.H + (long)k0 * w.ldh + c0, w.ldh, w.strideH,
+                      w.H + (long)r0 * w.ldh + c0, w.ldh, w.strideH, -1.0, 1, w.G, 0, false, false);
+    prof(w, KC_GEMM, 1, 8.0 * M * N * K * w.G, 16.0 * ((double)M * K + (double)K * N + 2.0 * M * N) * w.G);
+}
+
+static void lu_laswp(const LuWs& w, int k1, int k2, int c_lo, int c_hi) {
+    if (c_hi <= c_lo || k2 <= k1) return;
+    prof(w, KC_LASWP, 0);
+    dim3 grid((c_hi - c_lo + 255) / 256, w.G);
+    hipLaunchKernelGGL(laswp_kernel, grid, dim3(256), 0, w.st, w.H, w.ldh, w.strideH, w.ipiv, w.npad, k1, k2, c_lo, c_hi);
+    prof(w, KC_LASWP, 1, 0, 64.0 * (k2 - k1) * (c_hi - c_lo) * w.G);
+}
+
+static void lu_trsm(const LuWs& w, int j, int k, int c_lo, int c_hi) {
+    if (c_hi <= c_lo) return;
+    if (k <= NBP) {
+        prof(w, KC_TRSM, 0);
+        dim3 grid((c_hi - c_lo + 255) / 256, w.G);
+        hipLaunchKernelGGL(trsm32_kernel, grid, dim3(256), 0, w.st, w.H, w.ldh, w.strideH, j, c_lo, c_hi);
+        prof(w, KC_TRSM, 1, 4.0 * NBP * NBP * (c_hi - c_lo) * w.G, 32.0 * NBP * (c_hi - c_lo) * w.G);
+        return;
+    }
+    int h = (k >= 64) ? (k / 64) * 32 : 32;
+    lu_trsm(w, j, h, c_lo, c_hi);
+    lu_gemm(w, j + h, j + k, c_lo, c_hi, j, j + h);
+    lu_trsm(w, j + h, k - h, c_lo, c_hi);
+}
+
+static void lu_panel(const LuWs& w, int j0) {
+    int m = w.npad - j0;
+    prof(w, KC_PANEL, 0);
+    dim3 grid(w.G), block(PT);
+    int rpt = (m + PT - 1) / PT;
+#define PANEL(R) hipLaunchKernelGGL((lu_panel_kernel<R>), grid, block, 0, w.st, w.H, w.ldh, w.strideH, j0, m, w.ipiv, w.npad, w.info)
+    if (rpt <= 1) PANEL(1); else if (rpt <= 2) PANEL(2); else if (rpt <= 4) PANEL(4); else PANEL(8);
+#undef PANEL
+    prof(w, KC_PANEL, 1, 8.0 * m * NBP * NBP / 2 * w.G, 16.0 * m * NBP * 8 * w.G);
+}
+
+static void lu_recurse(const LuWs& w, int j0, int wd) {
+    if (wd <= NBP) { lu_panel(w, j0); return; }
+    int h = (wd / 64) * 32;
+    lu_recurse(w, j0, h);
+    lu_laswp(w, j0, j0 + h, j0 + h, j0 + wd);
+    lu_trsm(w, j0, h, j0 + h, j0 + wd);
+    lu_gemm(w, j0 + h, w.npad, j0 + h, j0 + wd, j0, j0 + h);
+    lu_recurse(w, j0 + h, wd - h);
+    lu_laswp(w, j0 + h, j0 + wd, j0, j0 + h);
+}
+
+// Maximum rows the base panel can own (8 rows per thread x 512 threads)
+int maus_lu_max_npad() { return PT * 8; }
+
+// Factor all G matrices in the workspace and carry the augmented column through (L y = P b).
+void maus_lu_factor(const LuWs& w, int nbo) {
+    const int ncols = (int)w.ldh;                 // npad + 32
+    for (int J = 0; J < w.npad; J += nbo) {
+        int wd = (w.npad - J < nbo) ? (w.npad - J) : nbo;
+        lu_recurse(w, J, wd);
+        lu_laswp(w, J, J + wd, J + wd, ncols);
+        lu_trsm(w, J, wd, J + wd, ncols);
+        lu_gemm(w, J + wd, w.npad, J + wd, ncols, J, J + wd);
+    }
+}
+
+void maus_lu_backsolve(const LuWs& w, c128* Wpop, long ldw, const int* d_slots, c128* xout_dense) {
+    prof(w, KC_BACKSOLVE, 0);
+    size_t shm = sizeof(c128) * ((size_t)w.npad + NBP * (NBP + 1) + NBP);
+    static bool attr_set = false;
+    if (!attr_set) {   // up to ~83 KB of dynamic LDS at npad = 4096 (160 KB per CU on gfx950)
+        (void)hipFuncSetAttribute((const void*)backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(backsolve_kernel, dim3(w.G), dim3(256), shm, w.st, w.H, w.ldh, w.strideH, w.n, w.npad,
+                       Wpop, ldw, d_slots, xout_dense, w.flags);
+    prof(w, KC_BACKSOLVE, 1, 4.0 * w.npad * w.npad * w.G, 8.0 * w.npad * w.npad * w.G);
+}
+
+void maus_build_h(const LuWs& w, const c128* A, const c128* d_shift, const double* d_psi, int rhs_mode,
+                  const c128* X, long ldx, const int* d_slots, const c128* bvec, int pert_mode, const double* d_U) {
+    prof(w, KC_BUILD, 0);
+    hipLaunchKernelGGL(build_h_kernel, dim3(w.npad, w.G), dim3(256), 0, w.st, A, w.n, w.npad, w.ldh, w.strideH, w.H,
+                       d_shift, d_psi, rhs_mode, X, ldx, d_slots, bvec, pert_mode, d_U, w.flags);
+    prof(w, KC_BUILD, 1, 0, 32.0 * w.npad * w.ldh * w.G);
+}
+
+void maus_load_h(const LuWs& w, const c128* d_Ain, const c128* d_bin) {
+    hipLaunchKernelGGL(load_h_kernel, dim3(w.npad, w.G), dim3(256), 0, w.st, d_Ain, d_bin, w.n, w.npad, w.ldh, w.strideH, w.H, w.flags);
+}

@@ -1,0 +1,162 @@
+/* libmaus_hip -- C ABI of the MI355X (gfx950) hot path of MAUS.
+ *
+ * The reference (Kier73/Adaptive-Matrix-Solver, `Adaptive_Matrix_Solver_0.1.py`,
+ * cited as AMS:line) is pure Python with no FFI layer; the boundary below is what
+ * a ctypes binding of its per-candidate inner loop binds.
+ * Each entry point names the reference lines it replaces.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  Complex data is interleaved (re, im) double,
+ *    i.e. NumPy complex128, C-contiguous (row-major).
+ *  - Every function returns 0 on success, <0 on an API/HIP error
+ *    (maus_last_error() gives the text).  Nothing throws across the boundary.
+ *  - NUMERICAL failures are not errors: they come back per candidate in
+ *    `status[]` (0 ok; k>0 exact zero pivot at column k, LAPACK `info`
+ *    convention, AMS:59 -> LinAlgError; -1 non-finite input matrix/rhs, -2
+ *    non-finite result, AMS:94-95 -> ValueError), so the Python retry ladder
+ *    (AMS:98-104) is reproduced exactly.
+ *  - Host buffers are caller-owned.  Device buffers are owned by the context.
+ *  - One context per GPU, not thread-safe; calls are synchronous as seen by the
+ *    caller (work is enqueued on the context's own HIP stream and joined before
+ *    results are returned).
+ *  - A "slot" is a row of the device-resident population arrays (one candidate
+ *    vector per contiguous row).
+ */
+#ifndef MAUS_HIP_H
+#define MAUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct maus_ctx maus_ctx;
+
+/* population arrays (`which`) */
+enum { MAUS_POP_X = 0,   /* v_k (eig) / x_k (linear) / right_v_k (SVD)  AMS:120-121 */
+       MAUS_POP_U = 1,   /* u_k (SVD)                                    AMS:121 */
+       MAUS_POP_W = 2,   /* raw solver result new_vec_raw                AMS:278 */
+       MAUS_POP_Y = 3 }; /* scratch: last A@X product */
+
+/* residual kinds (AMS:295-301) */
+enum { MAUS_EIG = 1, MAUS_LINEAR = 2, MAUS_SVD = 3 };
+
+/* perturbation modes of the dense regulariser (AMS:49-50) */
+enum { MAUS_PERT_NONE = 0,      /* reg = psi*I only (the 0.15*psi random term is dropped; the caller still
+                                   advances the NumPy stream)                                              */
+       MAUS_PERT_UNIFORM = 1,   /* caller supplies the two rand(N,N) draws; device forms
+                                   ((U1-.5)+i(U2-.5))*psi*0.15 with the reference's rounding order       */
+       MAUS_PERT_MT19937 = 2 }; /* device regenerates the legacy NumPy MT19937 stream from a supplied
+                                   624-word state per candidate (bit-identical draws)                    */
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int maus_ctx_create(int device, maus_ctx** out);
+int maus_ctx_destroy(maus_ctx* ctx);
+const char* maus_last_error(const maus_ctx* ctx);
+/* name_len bytes of device name, CU count, total and free HBM bytes */
+int maus_device_info(maus_ctx* ctx, char* name, int name_len, int* cus, size_t* hbm_total, size_t* hbm_free);
+/* library ABI version (compile-time constant) */
+int maus_abi_version(void);
+
+/* ---- problem data (AMS:343, 346: everything is complex128) -------------- */
+/* Upload the rows x cols problem matrix.  Replaces passing `current_matrix_A`
+ * by reference into every step (AMS:576). */
+int maus_set_matrix(maus_ctx* ctx, const double* a_c128, int rows, int cols);
+/* Upload b (AMS:146, 275). */
+int maus_set_rhs(maus_ctx* ctx, const double* b_c128, int n);
+
+/* ---- device-resident population ----------------------------------------- */
+int maus_pop_reserve(maus_ctx* ctx, int capacity);
+int maus_pop_capacity(maus_ctx* ctx);
+/* host (count x len, C-contiguous complex128) -> slots[i] of array `which`; len = vector length */
+int maus_pop_put(maus_ctx* ctx, int which, const int* slots, int count, const double* host_c128, int len);
+int maus_pop_get(maus_ctx* ctx, int which, const int* slots, int count, double* host_c128, int len);
+
+/* ---- phases of update_solution_step, batched over `count` candidates ---- */
+/* Y[slot] = A @ X[slot]; num = vdot(v, A@v), den = vdot(v, v)      AMS:264-268.
+ * num_c128: count complex; den_c128: count complex (imag is the rounded sum, ~0). */
+int maus_matvec_rayleigh(maus_ctx* ctx, const int* slots, int count, double* num_c128, double* den_c128);
+
+/* Psi-regularised direct solve, one LU per candidate            AMS:44-59 (+270):
+ *   H_k = (A - shift_k I) + (psi_k I + pert_k);   solve H_k w = rhs;   W[slot] <- w
+ * rhs_mode 0: rhs = X[slot] (eig, AMS:271); 1: rhs = b (linear, AMS:275).
+ * shift_c128[count] complex (0 for linear), psi[count] real.
+ * pert: see MAUS_PERT_*; `pert_data` is
+ *   UNIFORM: host double[count][2][n][n]   (U1 then U2 per candidate)
+ *   MT19937: host uint32[count][625]       (624 key words + position; state at the
+ *            start of the candidate's draws)
+ * status[count]: see conventions. */
+int maus_shifted_lu_solve(maus_ctx* ctx, const int* slots, int count, const double* shift_c128,
+                          const double* psi, int rhs_mode, int pert_mode, const void* pert_data,
+                          int32_t* status);
+
+/* X[slot] <- (1-alpha) X[slot] + alpha W[slot]; norm_out = ||X||_2; if normalise and
+ * norm > 1e-10: X *= 1/norm                                        AMS:280-285.
+ * alpha_c128[count] complex.  Slots whose norm test fails are left un-normalised (the
+ * host re-initialises them, AMS:283). */
+int maus_relax_normalise(maus_ctx* ctx, const int* slots, int count, const double* alpha_c128,
+                         int normalise, double* norm_out);
+
+/* residual_k and the finite check                                  AMS:295-301, 319-327.
+ * kind EIG: ||A v - lam v||; LINEAR: ||A x - b||; SVD: ||A v - s u|| + ||A^H u - s v||
+ * (lam_c128[count]: lambda or sigma+0i).  finite_out[i]=1 iff every entry of the
+ * candidate's vectors is finite. */
+int maus_residual(maus_ctx* ctx, int kind, const int* slots, int count, const double* lam_c128,
+                  double* resid_out, int32_t* finite_out);
+
+/* SVD alternating power step                                       AMS:233-242:
+ * t = A v; sigma1 = ||t||; u = t / (sigma1 > 1e-10 ? sigma1 : 1); s = A^H u;
+ * sigma2 = ||s||; v = s / (sigma2 > 1e-10 ? sigma2 : 1).
+ * Outputs per candidate: norms[4] = {||v_in||, sigma1, ||u||, sigma2}. */
+int maus_svd_power_step(maus_ctx* ctx, const int* slots, int count, double* norms_out);
+
+/* Hermitian shortcut                                               AMS:165-175:
+ * given the eigenvector matrix V (n x n, columns = eigenvectors, uploaded once
+ * per matrix version with maus_set_eigvecs) pick argmax_j |v^H V[:,j]| per
+ * candidate, copy that column into X[slot], normalise.  idx_out[count]. */
+int maus_set_eigvecs(maus_ctx* ctx, const double* v_c128, int n);
+int maus_herm_match(maus_ctx* ctx, const int* slots, int count, int32_t* idx_out, double* norm_out);
+
+/* Batched restarted GMRES with optional Jacobi preconditioner       AMS:60-90 ->
+ * scipy/sparse/linalg/_isolve/iterative.py:692-841 (restart 20, MGS, Givens, ptol).
+ *   H_k = A - shift_k I + psi_k I (MAUS_PERT_NONE only); x0 = rhs; W[slot] <- x
+ * use_jacobi[count]: 1 -> M = diag(1/diag H_k) (caller applies AMS:65/72 gating via
+ * jacobi_ok_out of a previous call or maus_diag_check).
+ * info_out: 0 converged, maxiter otherwise (SciPy convention); inner_out: inner iterations. */
+int maus_gmres(maus_ctx* ctx, const int* slots, int count, const double* shift_c128, const double* psi,
+               int rhs_mode, const int32_t* use_jacobi, double rtol, int restart, int maxiter,
+               int32_t* info_out, int32_t* inner_out, int32_t* status);
+/* AMS:67-72 gate: ok[i]=1 iff all 1/diag(H_k) finite and all |diag(H_k)| > 1e-12 */
+int maus_jacobi_check(maus_ctx* ctx, int count, const double* shift_c128, const double* psi, int32_t* ok);
+
+/* ---- plain batched GEMM on the context's stream (tests, Gram blocks) ----- */
+/* C[M,N] = alpha * opA(A)[M,K] * opB(B) + beta * C, host in/out, row-major complex128.
+ * b_layout 0: B is K x N; 1: B is N x K (dot-product form).  conj flags apply to A / B. */
+int maus_zgemm_host(maus_ctx* ctx, int M, int N, int K, const double* A, const double* B, double* C,
+                    int b_layout, int conj_a, int conj_b, double alpha, int beta);
+/* LU factor + solve of `count` dense n x n systems given on the host (tests):
+ * a_c128[count][n][n], b_c128[count][n] -> x_c128[count][n], status[count]. */
+int maus_lu_solve_host(maus_ctx* ctx, int count, int n, const double* a_c128, const double* b_c128,
+                       double* x_c128, int32_t* status, int32_t* ipiv_out /* count*n or NULL */);
+
+/* ---- measurement --------------------------------------------------------- */
+/* HIP-event timing on the context's stream. */
+int maus_timer_start(maus_ctx* ctx);
+int maus_timer_stop(maus_ctx* ctx, float* ms_out);
+/* Per-kernel-class accounting (event pairs around each launch of the class while enabled).
+ * classes: 0 zgemm (LU trailing update / A@X), 1 lu_panel, 2 trsm, 3 laswp, 4 build_H, 5 backsolve, 6 vector ops */
+int maus_profile_enable(maus_ctx* ctx, int on);
+int maus_profile_read(maus_ctx* ctx, int klass, int* launches, double* total_ms, double* flops, double* bytes);
+int maus_sync(maus_ctx* ctx);
+
+/* ---- legacy NumPy MT19937 stream helpers (host side) ----- */
+/* Advance a 624-word MT19937 key + position by `nwords` 32-bit outputs without
+ * materialising them (GF(2) jump polynomial; cached per nwords). */
+int maus_mt19937_jump(uint32_t* key624, int32_t* pos, uint64_t nwords);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAUS_HIP_H */
