@@ -370,7 +370,9 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
     if (check_slots(c, slots, count)) return -1;
     if (ensure_scalars(c, count)) return -1;
     if (ensure_lu_ws(c, n, count)) return -1;
-    const int Gmax = c->Hg;
+    // balanced chunks (271 candidates in a 256-matrix workspace run as 136 + 135, not 256 + 15)
+    const int nchunks = (count + c->Hg - 1) / c->Hg;
+    const int Gmax = (count + nchunks - 1) / nchunks;
     std::vector<int> h_info(Gmax), h_flags(Gmax);
     for (int off = 0; off < count; off += Gmax) {
         const int G = std::min(Gmax, count - off);

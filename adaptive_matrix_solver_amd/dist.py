@@ -1,0 +1,82 @@
+"""Population sharding across the GPUs of one node (one process per GPU, torch.distributed).
+
+The candidate step has no candidate<->candidate data flow: within an iteration
+every candidate reads (A, b, strategy) and its own state.  So the active candidates are
+block-partitioned over the ranks, every rank runs the batched HIP phases for its block only,
+and the per-candidate scalar records the host bookkeeping needs (Rayleigh dots, solve status,
+norms, residuals -- the inputs of landscape energy / stuckness) plus the updated candidate
+rows are exchanged with ONE kind of collective: an all-gather (RCCL over xGMI with the
+`nccl` backend; `gloo` in the CPU tests).  The host orchestration is replicated: every rank
+holds the same candidate list and consumes the same RNG streams, so bookkeeping is identical
+on all ranks by construction.  A is replicated (uploaded by each rank).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+class PopulationComm:
+    def __init__(self, device_tensors: bool | None = None):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.torch = torch
+        self.dist = dist
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+        backend = dist.get_backend()
+        self.on_device = (backend == "nccl") if device_tensors is None else device_tensors
+        self.device = None
+        if self.on_device:
+            self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        self.collectives = 0
+        self.bytes_gathered = 0
+
+    # ---- partition -------------------------------------------------------------------------
+    def owners(self, n_items: int) -> np.ndarray:
+        """Contiguous block partition of range(n_items) over the ranks (list order preserved)."""
+        base, extra = divmod(n_items, self.world)
+        sizes = [base + (1 if r < extra else 0) for r in range(self.world)]
+        return np.repeat(np.arange(self.world), sizes)
+
+    # ---- collective --------------------------------------------------------------------------
+    def allgather_rows(self, local: np.ndarray, counts) -> np.ndarray:
+        """local: (counts[rank], width) float64 -> (sum(counts), width), concatenated in rank order."""
+        torch = self.torch
+        width = local.shape[1] if local.ndim == 2 else 0
+        cmax = int(max(counts)) if len(counts) else 0
+        if cmax == 0 or width == 0:
+            return np.zeros((int(sum(counts)), width))
+        buf = np.zeros((cmax, width), dtype=np.float64)
+        buf[: local.shape[0]] = local
+        t = torch.from_numpy(buf)
+        if self.on_device:
+            t = t.to(self.device)
+        out = torch.empty((self.world * cmax, width), dtype=torch.float64, device=t.device)
+        self.dist.all_gather_into_tensor(out, t)
+        self.collectives += 1
+        self.bytes_gathered += out.numel() * 8
+        full = out.cpu().numpy().reshape(self.world, cmax, width)
+        return np.concatenate([full[r, : counts[r]] for r in range(self.world)], axis=0)
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def init_from_env(backend: str | None = None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun) if world > 1."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend)
+    return PopulationComm()

@@ -1,0 +1,671 @@
+"""Host-side mirror of the reference API for the MAUS hot path.
+
+Same names, arguments, attributes and error behaviour as the reference's
+`InverseIterateSolver` (AMS:30-104), `SolutionCandidate` (AMS:107-337) and `MAUS_Solver`
+(AMS:340-608) -- AMS = Kier73/Adaptive-Matrix-Solver `Adaptive_Matrix_Solver_0.1.py` --
+so user code switches by changing the import.  All matrix-sized arithmetic of the
+candidate step runs in HIP kernels behind `libmaus_hip.so` (engine.py / _cabi.py); the
+orchestration the reference keeps in Python (candidate spawn/retire, Psi aggression,
+alpha adaptation, landscape-energy bookkeeping, both RNG streams) stays here, in the
+reference's order, so bookkeeping is reproduced exactly.
+
+Documented deviations:
+  F1  evolve() defines the `target_sols_final` the reference forgot (= target_sols_disp).
+  F2  `gmres_compat='rtol'` (default) honours the evident intent of `tol=1e-8`;
+      `'scipy-legacy'` reproduces SciPy>=1.14 behaviour (TypeError swallowed -> LU).
+  F5  the Hermitian eigendecomposition is computed once per matrix, not once per candidate.
+  Sparse inputs are out of scope (dense BASELINE configs only) and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import random
+from enum import Enum
+
+import numpy as np
+
+from . import _cabi
+from ._cabi import POP_U, POP_X
+from .engine import DIRECT, GMRES, DeviceEngine, _advance_numpy_stream
+
+
+class ProblemType(Enum):                     # AMS:10-13
+    EIGENVALUE = 1
+    SOLVE_LINEAR_SYSTEM = 2
+    SVD = 3
+
+
+# AMS:16-26
+GLOBAL_DEFAULT_PSI_EPSILON_BASE = np.complex128(1e-20)
+GLOBAL_DEFAULT_ALPHA_V_INITIAL = np.complex128(0.01)
+GLOBAL_MAX_PSI_ATTEMPTS = 25
+GLOBAL_MAX_STUCK_FOR_RETIREMENT = 8
+GLOBAL_MIN_WEIGHT_TO_SURVIVE_PRUNE = 1e-10
+GLOBAL_VECTOR_SIMILARITY_TOL = 0.999
+GLOBAL_LAMBDA_SIMILARITY_TOL = 1e-5
+GLOBAL_SIGMA_SIMILARITY_TOL_ABS = 1e-6
+GLOBAL_SIGMA_SIMILARITY_TOL_REL = 1e-4
+GLOBAL_CONVERGENCE_RESIDUAL_TOL = 1e-8
+GLOBAL_MAX_STUCK_FOR_PRUNING = 4
+
+
+def _is_sparse(M) -> bool:
+    try:
+        import scipy.sparse as sp
+        return sp.issparse(M)
+    except Exception:
+        return False
+
+
+# ==========================================================================================
+# InverseIterateSolver (AMS:30-104)
+# ==========================================================================================
+class InverseIterateSolver:
+    """Psi-escalating regularised solve of (A_target + psi*I + pert) x = b on the GPU."""
+
+    _engine = None          # private context: every call uploads its own A_target
+
+    def __init__(self, N, base_psi_epsilon, max_attempts, preferred_method="direct_solve", is_sparse=False,
+                 gmres_compat="rtol", pert_mode="uniform"):
+        self.N = N
+        self.base_psi_epsilon = base_psi_epsilon
+        self.max_attempts = max_attempts
+        self.preferred_method = preferred_method
+        self.fallback_method = "iterative_gmres" if preferred_method == "direct_solve" else "direct_solve"
+        self.is_sparse = is_sparse
+        self.gmres_compat = gmres_compat
+        self.pert_mode = pert_mode
+        self.last_trace = []
+
+    @classmethod
+    def _ctx(cls):
+        if cls._engine is None:
+            cls._engine = _cabi.Context(0)
+        return cls._engine
+
+    def solve(self, A_target, b_rhs, candidate_stuck_counter):
+        if self.is_sparse or _is_sparse(A_target):
+            raise NotImplementedError("sparse problems are outside the MI355X hot path (dense only)")
+        ctx = self._ctx()
+        n = self.N
+        A_target = np.ascontiguousarray(A_target, dtype=np.complex128)
+        ctx.set_matrix(A_target)
+        ctx.set_rhs(np.ascontiguousarray(b_rhs, dtype=np.complex128))
+        ctx.pop_reserve(1)
+        ctx.pop_put(POP_X, [0], np.ascontiguousarray(b_rhs, dtype=np.complex128))     # x0 = b (AMS:61)
+        uniform = self.pert_mode == "uniform"
+        num_psi_attempts = 0
+        method = self.preferred_method
+        self.last_trace = []
+        zero = np.zeros(1, dtype=np.complex128)
+        while num_psi_attempts < self.max_attempts:                                    # AMS:43
+            psi = self.base_psi_epsilon * (10 ** (num_psi_attempts / 2.0)) * (10 ** (candidate_stuck_counter / 3.0))
+            pert_data = None
+            if uniform:
+                pert_data = np.empty((1, 2, n, n))
+                pert_data[0, 0] = np.random.rand(n, n)                                 # AMS:49
+                pert_data[0, 1] = np.random.rand(n, n)
+            else:
+                _advance_numpy_stream(4 * n * n)
+            ps = np.array([complex(psi).real])
+            rec = {"method": method, "attempt": num_psi_attempts, "psi": psi}
+            try:
+                if method == "direct_solve":
+                    st = ctx.shifted_lu_solve([0], zero, ps, rhs_mode=1,
+                                              pert_mode=_cabi.PERT_UNIFORM if uniform else _cabi.PERT_NONE,
+                                              pert_data=pert_data)[0]
+                    if st > 0:
+                        raise np.linalg.LinAlgError("Matrix is singular.")
+                    if st == -1:
+                        raise ValueError("array must not contain infs or NaNs")
+                    if st == -2:
+                        raise ValueError("Solution vector not finite after solve.")
+                elif method == "iterative_gmres":
+                    if self.gmres_compat == "scipy-legacy":
+                        raise TypeError("gmres() got an unexpected keyword argument 'tol'")
+                    use_j = np.zeros(1, dtype=np.int32)
+                    if candidate_stuck_counter > 1 and n > 0 and ctx.jacobi_check(zero, ps)[0]:     # AMS:65-72
+                        use_j[0] = 1
+                    rec["jacobi"] = bool(use_j[0])
+                    info, inner, status = ctx.gmres([0], zero, ps, 1, use_j)
+                    rec["info"], rec["inner"] = int(info[0]), int(inner[0])
+                    if status[0] == -1:
+                        raise ValueError("array must not contain infs or NaNs")
+                    if info[0] != 0:
+                        raise np.linalg.LinAlgError(f"GMRES did not converge cleanly (info={info[0]}). "
+                                                    f"Preconditioned: {'Yes' if use_j[0] else 'No'}")
+                    if status[0] == -2:
+                        raise ValueError("Solution vector not finite after solve.")
+                else:
+                    raise ValueError(f"Unknown solver method: {method}")
+                rec["ok"] = True
+                self.last_trace.append(rec)
+                x = ctx.pop_get(_cabi.POP_W, [0], n)[0]
+                return x, num_psi_attempts                                             # AMS:97
+            except (np.linalg.LinAlgError, ValueError, TypeError):
+                rec["ok"] = False
+                self.last_trace.append(rec)
+                if method == self.preferred_method and self.preferred_method != self.fallback_method and num_psi_attempts == 0:
+                    method = self.fallback_method
+                    num_psi_attempts = 0
+                    continue
+                num_psi_attempts += 1
+        raise RuntimeError(f"InverseIterateSolver failed all {self.max_attempts} attempts for "
+                           f"{self.preferred_method} and {self.fallback_method}.")
+
+
+# ==========================================================================================
+# SolutionCandidate (AMS:107-337)
+# ==========================================================================================
+class SolutionCandidate:
+    _candidate_id_counter = 0
+
+    class State(Enum):
+        EXPLORING = 1
+        REFINING = 2
+        STUCK = 3
+        CONVERGED = 4
+        RETIRED = 5
+
+    def __init__(self, problem_matrix, problem_type, N_diag, initial_lambda=None, initial_v=None, initial_x=None,
+                 initial_u=None, initial_sigma=None, initial_weight=0.01, *, engine=None, record_history=None):
+        self.id = SolutionCandidate._candidate_id_counter
+        SolutionCandidate._candidate_id_counter += 1
+        self.N_diag = N_diag
+        self.M_rows, self.M_cols = problem_matrix.shape
+        self.problem_type = problem_type
+        self.problem_matrix = problem_matrix
+        self.b_vector = None
+        self.lambda_k = initial_lambda
+        self.sigma_k = initial_sigma
+        # host mirrors of the device rows; _hv = POP_X row (v_k | x_k | right_v_k), _hu = POP_U row (u_k)
+        self._hv = None
+        self._hu = None
+        self._host_valid = True        # host mirrors are current
+        self._dev_valid = False        # device rows are current
+        self._slot = None
+        self._engine = None
+        self._record = (max(self.M_rows, self.M_cols) <= 512) if record_history is None else bool(record_history)
+        self.state = SolutionCandidate.State.EXPLORING
+        self.w_k = initial_weight
+        self.residual_k = float("inf")
+        self.prev_residual = float("inf")
+        self.alpha_local_step = GLOBAL_DEFAULT_ALPHA_V_INITIAL
+        self.stuck_counter = 0
+        self.local_psi_retries_needed = 0
+        self.num_resets = 0
+        self.param_history = []
+        self.residual_history = []
+        (engine or DeviceEngine.default()).attach(self)
+        self.initialize_random_solution()                     # overwrites any seeds (AMS:127)
+
+    # ---- host <-> device mirrors --------------------------------------------------------------
+    def _len_v(self):
+        return self.M_cols if self.problem_type == ProblemType.SVD else self.N_diag
+
+    def _pull(self):
+        if not self._host_valid:
+            ctx = self._engine.ctx
+            self._hv = ctx.pop_get(POP_X, [self._slot], self._len_v())[0]
+            if self.problem_type == ProblemType.SVD:
+                self._hu = ctx.pop_get(POP_U, [self._slot], self.M_rows)[0]
+            self._host_valid = True
+
+    def _push(self, force=False):
+        if force or not self._dev_valid:
+            ctx = self._engine.ctx
+            if self._hv is not None:
+                ctx.pop_put(POP_X, [self._slot], self._hv)
+            if self._hu is not None and self.problem_type == ProblemType.SVD:
+                ctx.pop_put(POP_U, [self._slot], self._hu)
+            self._dev_valid = True
+
+    def _invalidate(self):
+        """The device rows were updated by a kernel: host mirrors are stale."""
+        self._host_valid = False
+        self._dev_valid = True
+
+    def _restore_device(self):
+        """Undo a speculative device update from the (pre-step) host mirrors."""
+        assert self._hv is not None
+        self._host_valid = True
+        self._push(force=True)
+
+    def _set_vec(self, name, value):
+        self._pull()
+        setattr(self, name, None if value is None else np.asarray(value, dtype=np.complex128))
+        self._host_valid = True
+        self._dev_valid = False
+
+    @property
+    def v_k(self):
+        if self.problem_type != ProblemType.EIGENVALUE:
+            return None
+        self._pull()
+        return self._hv
+
+    @v_k.setter
+    def v_k(self, value):
+        if self.problem_type == ProblemType.EIGENVALUE:
+            self._set_vec("_hv", value)
+
+    @property
+    def x_k(self):
+        if self.problem_type != ProblemType.SOLVE_LINEAR_SYSTEM:
+            return None
+        self._pull()
+        return self._hv
+
+    @x_k.setter
+    def x_k(self, value):
+        if self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
+            self._set_vec("_hv", value)
+
+    @property
+    def right_v_k(self):
+        if self.problem_type != ProblemType.SVD:
+            return None
+        self._pull()
+        return self._hv
+
+    @right_v_k.setter
+    def right_v_k(self, value):
+        if self.problem_type == ProblemType.SVD:
+            self._set_vec("_hv", value)
+
+    @property
+    def u_k(self):
+        if self.problem_type != ProblemType.SVD:
+            return None
+        self._pull()
+        return self._hu
+
+    @u_k.setter
+    def u_k(self, value):
+        if self.problem_type == ProblemType.SVD:
+            self._set_vec("_hu", value)
+
+    # ---- AMS:129-143 -----------------------------------------------------------------------------
+    def initialize_random_solution(self):
+        rand_vec_init = lambda N: (np.random.rand(N) + 1j * np.random.rand(N)).astype(np.complex128)
+
+        def norm_rand_vec(v):
+            if np.linalg.norm(v) > 1e-10:
+                return v / np.linalg.norm(v)
+            w = rand_vec_init(v.shape[0])
+            return w / np.linalg.norm(rand_vec_init(v.shape[0]))
+
+        if self.problem_type == ProblemType.EIGENVALUE:
+            self.v_k = norm_rand_vec(rand_vec_init(self.N_diag))
+            self.lambda_k = (random.random() * 5 - 2.5 + 1j * (random.random() * 5 - 2.5))
+        elif self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
+            self.x_k = norm_rand_vec(rand_vec_init(self.N_diag)) * random.uniform(0.1, 10.0)
+        elif self.problem_type == ProblemType.SVD:
+            self.u_k = norm_rand_vec(rand_vec_init(self.M_rows))
+            self.right_v_k = norm_rand_vec(rand_vec_init(self.M_cols))
+            self.sigma_k = 1.0
+        self._push(force=True)
+        self.param_history.append(self.get_current_solution_params())
+        self.residual_history.append(self.residual_k)
+
+    def _record_history(self):
+        """AMS:303-304 (vectors are recorded only when record_history is on)."""
+        if self._record:
+            self.param_history.append(self.get_current_solution_params())
+        self.residual_history.append(self.residual_k)
+
+    # ---- AMS:145-331 -----------------------------------------------------------------------------
+    def update_solution_step(self, current_matrix_A, b_vector=None, strat_params=None, global_knowledge=None):
+        if _is_sparse(current_matrix_A) or global_knowledge.get("is_sparse_problem", False):
+            raise NotImplementedError("sparse problems are outside the MI355X hot path (dense only)")
+        self._engine.step([self], current_matrix_A, b_vector, strat_params, global_knowledge)
+
+    def get_current_solution_params(self):                      # AMS:333-337
+        if self.problem_type == ProblemType.EIGENVALUE:
+            return (self.lambda_k, self.v_k)
+        elif self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
+            return (self.x_k,)
+        elif self.problem_type == ProblemType.SVD:
+            return (self.sigma_k, self.u_k, self.right_v_k)
+        return None
+
+
+# ==========================================================================================
+# MAUS_Solver (AMS:340-608)
+# ==========================================================================================
+class MAUS_Solver:
+    def __init__(self, problem_matrix, problem_type, b_vector=None, initial_num_candidates=None,
+                 global_convergence_tol=1e-8, *, device=0, pert_mode="auto", gmres_compat="rtol",
+                 record_history=None, comm=None, quiet=False):
+        if _is_sparse(problem_matrix):
+            raise NotImplementedError("sparse problems are outside the MI355X hot path (dense only)")
+        self.M = problem_matrix.astype(np.complex128)                                   # AMS:343
+        self.N_rows, self.N_cols = self.M.shape
+        self.N_diag = self.N_rows
+        self.problem_type = problem_type
+        self.b = b_vector.astype(np.complex128) if b_vector is not None else None
+        self.diag_info = self._diagnose_matrix_initial(self.M)
+        self.is_sparse_problem_init = self.diag_info["is_sparse_init"]
+        self.cond_number = self.diag_info["condition_number"]
+        self.problem_knowledge = {
+            "matrix_type": "Dense", "spectrum_hint": "Unknown", "numerical_stability_state": "Stable",
+            "local_solver_preference": "direct_solve", "effective_rank_SVD": min(self.N_rows, self.N_cols),
+            "true_matrix_is_singular": self.diag_info["is_singular"],
+            "is_sparse_problem": self.is_sparse_problem_init,
+            "is_hermitian": self.diag_info.get("is_hermitian", False),
+            "is_complex_symmetric": self.diag_info.get("is_complex_symmetric", False),
+        }
+        if self.problem_knowledge["is_sparse_problem"]:
+            raise NotImplementedError("matrices < 25% dense take the reference's sparse path, which is out of scope")
+        self.strat_params = {
+            "overall_psi_aggression_factor": 1.0, "max_psi_retries": GLOBAL_MAX_PSI_ATTEMPTS,
+            "min_survival_weight": GLOBAL_MIN_WEIGHT_TO_SURVIVE_PRUNE, "spawn_rate_multiplier": 1.0,
+            "convergence_tolerance": global_convergence_tol, "current_convergence_threshold": global_convergence_tol,
+        }
+        self._set_initial_strategy()
+        self.engine = DeviceEngine(device=device, pert_mode=pert_mode, gmres_compat=gmres_compat, comm=comm)
+        self.engine.bind_matrix(self.M)
+        self._record_history = record_history
+        self._quiet = quiet
+        initial_num_candidates = initial_num_candidates if initial_num_candidates is not None else (self.N_diag * 3)
+        if self.problem_type == ProblemType.SVD:
+            initial_num_candidates = max(initial_num_candidates, min(self.N_rows, self.N_cols) * 3)
+        self.engine.ctx.pop_reserve(initial_num_candidates + 64)
+        self.candidates = [self._new_candidate() for _ in range(initial_num_candidates)]
+        SolutionCandidate._candidate_id_counter = initial_num_candidates              # AMS:368
+        if not quiet:
+            print(f"MAUS Initialized with {initial_num_candidates} candidates for {self.problem_type.name} "
+                  f"(Dims={self.N_rows}x{self.N_cols}).")
+            print(f"Initial matrix diagnostics: Cond={self.cond_number:.2e}, MatrixType={self.problem_knowledge['matrix_type']}, "
+                  f"Hermitian={self.problem_knowledge['is_hermitian']}. Stability: {self.problem_knowledge['numerical_stability_state']}.")
+        self.landscape_energy = 1.0
+        self.avg_residual = 1.0
+        self.avg_stuckness = 0.0
+        self.num_distinct_converged_solutions = 0
+        self.converged_solutions = []
+        self.true_solution = None
+        self.candidate_steps = 0
+
+    def _new_candidate(self, **kw):
+        return SolutionCandidate(self.M, self.problem_type, self.N_diag, engine=self.engine,
+                                 record_history=self._record_history, **kw)
+
+    # ---- AMS:374-404 (ndarray branch) ---------------------------------------------------------
+    def _diagnose_matrix_initial(self, matrix):
+        diag_info = {"is_hermitian": False, "is_complex_symmetric": False, "is_sparse_init": False,
+                     "condition_number": np.inf, "is_singular": False}
+        if isinstance(matrix, np.ndarray):
+            diag_info["is_sparse_init"] = (np.count_nonzero(matrix) / matrix.size) < 0.25 if matrix.size > 0 else False
+            try:
+                if matrix.ndim == 2 and matrix.shape[0] == matrix.shape[1]:
+                    if np.allclose(matrix, matrix.conj().T):
+                        diag_info["is_hermitian"] = True
+                    if np.allclose(matrix, matrix.T):
+                        diag_info["is_complex_symmetric"] = True
+            except Exception:
+                pass
+        cond_num_val = np.inf
+        is_singular_val = False
+        if (not diag_info["is_sparse_init"] and isinstance(matrix, np.ndarray) and matrix.ndim == 2
+                and matrix.shape[0] == matrix.shape[1] and matrix.size > 0):
+            try:
+                cond_num_val = np.linalg.cond(matrix)
+                if np.isinf(cond_num_val) or cond_num_val > 1e15:
+                    is_singular_val = True
+            except np.linalg.LinAlgError:
+                cond_num_val = np.inf
+                is_singular_val = True
+        diag_info["condition_number"] = cond_num_val
+        diag_info["is_singular"] = is_singular_val
+        return diag_info
+
+    # ---- AMS:406-422 ------------------------------------------------------------------------------
+    def _set_initial_strategy(self):
+        sp_, pk = self.strat_params, self.problem_knowledge
+        if self.cond_number > 1e12:
+            pk["numerical_stability_state"] = "Critical"
+            sp_["overall_psi_aggression_factor"] = 50.0
+            sp_["max_psi_retries"] = GLOBAL_MAX_PSI_ATTEMPTS * 2
+            sp_["current_convergence_threshold"] = 1e-2
+            pk["local_solver_preference"] = "iterative_gmres"
+        elif self.cond_number > 1e6:
+            pk["numerical_stability_state"] = "Fragile"
+            sp_["overall_psi_aggression_factor"] = 10.0
+            pk["local_solver_preference"] = "iterative_gmres"
+            sp_["current_convergence_threshold"] = 1e-4
+        else:
+            pk["numerical_stability_state"] = "Stable"
+            pk["local_solver_preference"] = "direct_solve"
+            sp_["current_convergence_threshold"] = sp_["convergence_tolerance"]
+        if self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM and self.diag_info.get("is_singular", False):
+            pk["true_matrix_is_singular"] = True
+            pk["local_solver_preference"] = "iterative_gmres"
+            sp_["overall_psi_aggression_factor"] = max(sp_["overall_psi_aggression_factor"], 20.0)
+        if self.problem_type == ProblemType.SVD:
+            if pk["numerical_stability_state"] == "Stable":
+                sp_["overall_psi_aggression_factor"] = max(sp_["overall_psi_aggression_factor"], 2.0)
+            sp_["current_convergence_threshold"] = max(1e-5, sp_["convergence_tolerance"])
+
+    # ---- AMS:424-475 ------------------------------------------------------------------------------
+    def _update_global_diagnostics(self, iteration):
+        C = SolutionCandidate.State
+        total_active_candidates = len(self.candidates)
+        sum_residuals = 0.0
+        sum_stuck_counters = 0
+        num_converged_all_types = 0
+        self.num_distinct_converged_solutions = 0
+        self.converged_solutions = []
+        current_sigma_magnitudes = []
+        thr = self.strat_params["current_convergence_threshold"]
+        for c in self.candidates:
+            if c.state == C.CONVERGED:
+                num_converged_all_types += 1
+                current_tuple = c.get_current_solution_params()
+                is_distinct = True
+                if current_tuple is None or any(p is None for p in current_tuple):
+                    continue
+                if self.problem_type == ProblemType.EIGENVALUE:
+                    for s_item in self.converged_solutions:
+                        s_lam, s_vec = s_item[0], s_item[1]
+                        effective_tol = GLOBAL_LAMBDA_SIMILARITY_TOL + np.abs(s_lam) * 1e-6
+                        if (np.abs(current_tuple[0] - s_lam) < effective_tol
+                                and np.abs(np.vdot(current_tuple[1], s_vec)) > GLOBAL_VECTOR_SIMILARITY_TOL):
+                            is_distinct = False
+                            break
+                elif self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
+                    if (len(self.converged_solutions) > 0 and
+                            np.linalg.norm(current_tuple[0] - self.converged_solutions[0][0])
+                            < self.strat_params["convergence_tolerance"] * 100):
+                        is_distinct = False
+                elif self.problem_type == ProblemType.SVD:
+                    max_s = max((cand.sigma_k.real for cand in self.candidates
+                                 if cand.sigma_k is not None and cand.sigma_k.real > 0), default=1.0)
+                    if current_tuple[0].real / max_s < GLOBAL_SIGMA_SIMILARITY_TOL_REL:
+                        is_distinct = False
+                    if is_distinct:
+                        for s_item in self.converged_solutions:
+                            s_sigma, s_u, s_v = s_item
+                            if (np.abs(current_tuple[0] - s_sigma) < max(GLOBAL_SIGMA_SIMILARITY_TOL_ABS, s_sigma * GLOBAL_SIGMA_SIMILARITY_TOL_REL)
+                                    and np.abs(np.vdot(current_tuple[1], s_u)) > GLOBAL_VECTOR_SIMILARITY_TOL
+                                    and np.abs(np.vdot(current_tuple[2], s_v)) > GLOBAL_VECTOR_SIMILARITY_TOL):
+                                is_distinct = False
+                                break
+                    current_sigma_magnitudes.append(current_tuple[0].real)
+                if is_distinct:
+                    self.converged_solutions.append(current_tuple)
+                    self.num_distinct_converged_solutions += 1
+            if c.state not in (C.CONVERGED, C.RETIRED):
+                sum_residuals += c.residual_k if np.isfinite(c.residual_k) else (thr * 100)
+                sum_stuck_counters += c.stuck_counter
+        non_conv_retired_count = max(1, total_active_candidates - num_converged_all_types)
+        self.avg_residual = sum_residuals / non_conv_retired_count
+        self.avg_stuckness = sum_stuck_counters / non_conv_retired_count
+        norm_avg_res = self.avg_residual / (thr * 10)
+        norm_avg_stuck = self.avg_stuckness / (GLOBAL_MAX_STUCK_FOR_RETIREMENT * 2)
+        target_sols_N_global = self.N_diag
+        if self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
+            target_sols_N_global = 1
+        elif self.problem_type == ProblemType.SVD:
+            if len(current_sigma_magnitudes) > 1:
+                sorted_sigmas = sorted([s for s in current_sigma_magnitudes if s > GLOBAL_SIGMA_SIMILARITY_TOL_ABS], reverse=True)
+                if sorted_sigmas:
+                    max_sigma_val = sorted_sigmas[0]
+                    rank_detected = sum(1 for s_val in sorted_sigmas if s_val / max_sigma_val > GLOBAL_SIGMA_SIMILARITY_TOL_REL)
+                    self.problem_knowledge["effective_rank_SVD"] = min(
+                        rank_detected if rank_detected > 0 else 1, min(self.N_rows, self.N_cols),
+                        max(1, self.problem_knowledge.get("effective_rank_SVD", 1)))
+            target_sols_N_global = self.problem_knowledge.get("effective_rank_SVD", min(self.N_rows, self.N_cols))
+        norm_missing_sols = (target_sols_N_global - self.num_distinct_converged_solutions) / max(1, target_sols_N_global)
+        self.landscape_energy = max(0.0, min(1.0, (norm_avg_res * 0.4) + (norm_avg_stuck * 0.3) + (norm_missing_sols * 0.3)))
+        if self.avg_stuckness > GLOBAL_MAX_STUCK_FOR_RETIREMENT * 0.5:
+            self.problem_knowledge["numerical_stability_state"] = "Critical"
+        elif self.avg_stuckness > GLOBAL_MAX_STUCK_FOR_PRUNING * 0.5:
+            self.problem_knowledge["numerical_stability_state"] = "Fragile"
+        else:
+            self.problem_knowledge["numerical_stability_state"] = "Stable"
+
+    # ---- AMS:477-501 ------------------------------------------------------------------------------
+    def _adjust_global_strategy(self, iteration):
+        sp_, pk = self.strat_params, self.problem_knowledge
+        stab = pk["numerical_stability_state"]
+        tol = sp_["convergence_tolerance"]
+        if self.landscape_energy > 0.6 and stab == "Critical":
+            pk["local_solver_preference"] = "iterative_gmres"
+            sp_["overall_psi_aggression_factor"] = min(200.0, sp_["overall_psi_aggression_factor"] * 1.1)
+            sp_["spawn_rate_multiplier"] = min(10.0, sp_["spawn_rate_multiplier"] * 1.2)
+            sp_["current_convergence_threshold"] = max(tol * 50, sp_["current_convergence_threshold"] * 1.05)
+        elif self.landscape_energy > 0.4 and stab == "Fragile":
+            pk["local_solver_preference"] = "iterative_gmres"
+            sp_["overall_psi_aggression_factor"] = min(50.0, sp_["overall_psi_aggression_factor"] * 1.05)
+            sp_["spawn_rate_multiplier"] = min(5.0, sp_["spawn_rate_multiplier"] * 1.1)
+            sp_["current_convergence_threshold"] = max(tol * 5, sp_["current_convergence_threshold"] * 1.02)
+        elif self.landscape_energy < 0.2 and stab == "Stable":
+            pk["local_solver_preference"] = "direct_solve"
+            sp_["overall_psi_aggression_factor"] = max(1.0, sp_["overall_psi_aggression_factor"] * 0.9)
+            sp_["spawn_rate_multiplier"] = max(0.01, sp_["spawn_rate_multiplier"] * 0.9)
+            sp_["current_convergence_threshold"] = max(tol, sp_["current_convergence_threshold"] * 0.9)
+        sp_["overall_psi_aggression_factor"] = max(1.0, min(200.0, sp_["overall_psi_aggression_factor"]))
+        sp_["spawn_rate_multiplier"] = max(0.01, min(10.0, sp_["spawn_rate_multiplier"]))
+        sp_["current_convergence_threshold"] = max(tol, min(1.0, sp_["current_convergence_threshold"]))
+
+    # ---- AMS:504-549 ------------------------------------------------------------------------------
+    def _manage_candidates(self, iteration):
+        C = SolutionCandidate.State
+        survivors = []
+        sorted_candidates = sorted(self.candidates,
+                                   key=lambda x: (-x.w_k, x.residual_k if np.isfinite(x.residual_k) else float("inf")))
+        tol = self.strat_params["convergence_tolerance"]
+        for c in sorted_candidates:
+            redundant = False
+            if c.state == C.CONVERGED:
+                for s_c in survivors:
+                    if s_c.state != C.CONVERGED:
+                        continue
+                    tc, ts = c.get_current_solution_params(), s_c.get_current_solution_params()
+                    if tc is None or ts is None or any(p is None for p in tc) or any(p is None for p in ts):
+                        continue
+                    if self.problem_type == ProblemType.EIGENVALUE:
+                        if (np.abs(tc[0] - ts[0]) < (GLOBAL_LAMBDA_SIMILARITY_TOL + np.abs(ts[0]) * 1e-6)
+                                and np.abs(np.vdot(tc[1], ts[1])) > GLOBAL_VECTOR_SIMILARITY_TOL):
+                            redundant = True
+                            break
+                    elif self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
+                        if np.linalg.norm(tc[0] - ts[0]) < tol * 10:
+                            redundant = True
+                            break
+                    elif self.problem_type == ProblemType.SVD:
+                        if ts[0].real < GLOBAL_SIGMA_SIMILARITY_TOL_ABS / 100:
+                            redundant = False
+                        elif (np.abs(tc[0] - ts[0]) < max(GLOBAL_SIGMA_SIMILARITY_TOL_ABS, ts[0] * GLOBAL_SIGMA_SIMILARITY_TOL_REL)
+                              and np.abs(np.vdot(tc[1], ts[1])) > GLOBAL_VECTOR_SIMILARITY_TOL
+                              and np.abs(np.vdot(tc[2], ts[2])) > GLOBAL_VECTOR_SIMILARITY_TOL):
+                            redundant = True
+                            break
+            if redundant:
+                c.state = C.RETIRED
+            elif c.state == C.RETIRED:
+                pass
+            elif ((c.w_k < self.strat_params["min_survival_weight"] and c.state != C.CONVERGED)
+                  or (c.stuck_counter >= GLOBAL_MAX_STUCK_FOR_RETIREMENT and c.state != C.CONVERGED)):
+                c.state = C.RETIRED
+            else:
+                survivors.append(c)
+        self.candidates = survivors
+        target = self.N_diag
+        if self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
+            target = 1
+        elif self.problem_type == ProblemType.SVD:
+            target = self.problem_knowledge.get("effective_rank_SVD", min(self.N_rows, self.N_cols))
+        desired_pop_base = max(5, int(self.N_diag * 1.5 if self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM else self.N_diag * 2))
+        if self.problem_type == ProblemType.SVD:
+            desired_pop_base = max(desired_pop_base, int(target * 2.5))
+        num_to_spawn = max(0, desired_pop_base - len(self.candidates)) + max(0, target - self.num_distinct_converged_solutions)
+        num_to_spawn = min(int(num_to_spawn * self.strat_params["spawn_rate_multiplier"]), self.N_diag * 2, 15)
+        for _ in range(max(0, num_to_spawn)):
+            kw = {}
+            if self.num_distinct_converged_solutions > 0 and self.landscape_energy < 0.8 and self.converged_solutions:
+                base_sol_tuple = random.choice(self.converged_solutions)                       # E7
+                if base_sol_tuple is None or any(p is None for p in base_sol_tuple):
+                    continue
+                if self.problem_type == ProblemType.EIGENVALUE:
+                    kw["initial_lambda"] = base_sol_tuple[0] + (random.random() * 0.1 - 0.05 + 1j * (random.random() * 0.1 - 0.05)) * (0.1 + self.landscape_energy)
+                    v_pert = (np.random.rand(self.N_diag) - 0.5 + 1j * (np.random.rand(self.N_diag) - 0.5)) * (0.1 + self.landscape_energy)
+                    new_v = base_sol_tuple[1] + v_pert
+                    norm_new_v = np.linalg.norm(new_v)
+                    kw["initial_v"] = new_v / norm_new_v if norm_new_v > 1e-9 else \
+                        (np.random.rand(self.N_diag) + 1j * np.random.rand(self.N_diag)) / np.sqrt(self.N_diag)
+            new_candidate = self._new_candidate(**kw, initial_weight=0.01)
+            new_candidate.alpha_local_step = GLOBAL_DEFAULT_ALPHA_V_INITIAL * (1 + self.strat_params["overall_psi_aggression_factor"] / 10.0)
+            self.candidates.append(new_candidate)
+
+    # ---- the loop body AMS:573-577 ------------------------------------------------------------------
+    def step_population(self):
+        """The hot loop `for candidate in self.candidates: update_solution_step(...)`, batched."""
+        C = SolutionCandidate.State
+        active = [c for c in self.candidates if c.state not in (C.CONVERGED, C.RETIRED)]
+        self.engine.step(active, self.M, self.b, self.strat_params, self.problem_knowledge)
+        self.candidate_steps += len(active)
+        return len(active)
+
+    def loop_body(self, iteration):
+        self._update_global_diagnostics(iteration)
+        self._adjust_global_strategy(iteration)
+        n = self.step_population()
+        self._manage_candidates(iteration)
+        return n
+
+    # ---- AMS:551-608 ------------------------------------------------------------------------------
+    def evolve(self, max_iterations=100):
+        print(f"--- Starting MAUS Evolution for {max_iterations} iterations ({self.problem_type.name}) ---")
+        self.true_solution = None       # the reference's SciPy "true solution" prologue is reporting only
+        for i in range(max_iterations):
+            self.loop_body(i + 1)
+            target_sols_disp = self.N_diag
+            if self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
+                target_sols_disp = 1
+            elif self.problem_type == ProblemType.SVD:
+                target_sols_disp = self.problem_knowledge.get("effective_rank_SVD", min(self.N_rows, self.N_cols))
+            target_sols_final = target_sols_disp       # undefined in the reference (NameError at AMS:583)
+            if (i + 1) % 20 == 0 or i == max_iterations - 1:
+                print(f"Iter {i+1}/{max_iterations}: Energy={self.landscape_energy:.2f}, AvgRes={self.avg_residual:.2e}, "
+                      f"Conv={self.num_distinct_converged_solutions}/{target_sols_disp}, "
+                      f"Stab={self.problem_knowledge['numerical_stability_state']}")
+            if (self.num_distinct_converged_solutions >= target_sols_final and self.landscape_energy < 0.05
+                    and self.avg_residual < self.strat_params["convergence_tolerance"]):
+                print(f"MAUS converged early at iteration {i+1}.")
+                break
+            if i == max_iterations - 1 and self.num_distinct_converged_solutions < target_sols_final:
+                print(f"WARNING: Max iterations. Found {self.num_distinct_converged_solutions}/{target_sols_final}.")
+        print("--- MAUS Evolution COMPLETE ---")
+        print("Final Report:")
+        sols = self.converged_solutions
+        if self.problem_type == ProblemType.EIGENVALUE:
+            sols = sorted(sols, key=lambda x: (x[0].real, x[0].imag))
+        elif self.problem_type == ProblemType.SVD:
+            sols = sorted(sols, key=lambda x: -x[0].real)
+        for k, t in enumerate(sols):
+            if self.problem_type == ProblemType.EIGENVALUE:
+                print(f"  Eig {k+1}: λ={t[0]:.6e}")
+            elif self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
+                print(f"  LinSolve {k+1}: X_norm1={np.linalg.norm(t[0], 1):.6e}")
+            else:
+                print(f"  SVD {k+1}: σ={t[0]:.6e}")
