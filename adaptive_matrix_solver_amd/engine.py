@@ -296,8 +296,8 @@ class DeviceEngine:
                 self._svd(todo, A, strat)
             else:
                 self._solve(todo, A, b, strat, know)
+            self._sync_rows(todo)                       # peers' updated rows, before anything reads them back
             self._finish(todo, A, b, strat)
-        self._sync_rows(cands)
 
     # ---- Hermitian shortcut (AMS:155-221) ----------------------------------------------
     def _hermitian(self, cands, A):
@@ -319,6 +319,9 @@ class DeviceEngine:
         idx, _ = self.d_herm_match(cands)
         lam = evals[idx]
         res, _fin = self.d_residual(KIND_EIG, cands, lam.astype(np.complex128))
+        for c in cands:
+            c._invalidate()
+        self._sync_rows(cands)
         for k, c in enumerate(cands):
             c.lambda_k = lam[k]
             c._invalidate()

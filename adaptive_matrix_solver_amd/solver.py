@@ -335,7 +335,7 @@ class SolutionCandidate:
 class MAUS_Solver:
     def __init__(self, problem_matrix, problem_type, b_vector=None, initial_num_candidates=None,
                  global_convergence_tol=1e-8, *, device=0, pert_mode="auto", gmres_compat="rtol",
-                 record_history=None, comm=None, quiet=False):
+                 record_history=None, comm=None, quiet=False, engine=None):
         if _is_sparse(problem_matrix):
             raise NotImplementedError("sparse problems are outside the MI355X hot path (dense only)")
         self.M = problem_matrix.astype(np.complex128)                                   # AMS:343
@@ -362,7 +362,10 @@ class MAUS_Solver:
             "convergence_tolerance": global_convergence_tol, "current_convergence_threshold": global_convergence_tol,
         }
         self._set_initial_strategy()
-        self.engine = DeviceEngine(device=device, pert_mode=pert_mode, gmres_compat=gmres_compat, comm=comm)
+        # `engine` is a test seam (tests/fake_ctx.py drives the host logic without a GPU); product
+        # code never passes it, and DeviceEngine() raises if libmaus_hip / the device is missing
+        self.engine = engine if engine is not None else DeviceEngine(device=device, pert_mode=pert_mode,
+                                                                     gmres_compat=gmres_compat, comm=comm)
         self.engine.bind_matrix(self.M)
         self._record_history = record_history
         self._quiet = quiet

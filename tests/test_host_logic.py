@@ -1,0 +1,146 @@
+"""The product's HOST logic (solver.py + engine.py) against the fixtures captured from the
+reference, on CPU: the device phases are replaced by the NumPy test double tests/fake_ctx.py,
+so everything that must be bit-exact -- both RNG streams, the retry/fallback ladder, alpha /
+state machine, diagnostics, strategy, retire/spawn -- is checked digest by digest."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import scenarios
+import snapshot
+from fake_ctx import FakeContext
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def make_solver(name, **kw):
+    from adaptive_matrix_solver_amd.engine import DeviceEngine
+    from adaptive_matrix_solver_amd.solver import MAUS_Solver, ProblemType, SolutionCandidate
+    spec = scenarios.TRAJECTORIES[name]
+    A, b = scenarios.build(spec)
+    np.random.seed(spec["seed"]); random.seed(spec["seed"]); SolutionCandidate._candidate_id_counter = 0
+    PT = {"eig": ProblemType.EIGENVALUE, "lin": ProblemType.SOLVE_LINEAR_SYSTEM, "svd": ProblemType.SVD}[spec["kind"]]
+    eng = DeviceEngine(ctx=FakeContext(), pert_mode=kw.pop("pert_mode", "uniform"),
+                       gmres_compat=kw.pop("gmres_compat", "scipy-legacy"), comm=kw.pop("comm", None))
+    return MAUS_Solver(A, PT, b_vector=b, initial_num_candidates=spec["P"], global_convergence_tol=spec["tol"],
+                       quiet=True, engine=eng, record_history=True), spec
+
+
+def rows_of(cands, kind):
+    rows = []
+    for c in cands:
+        if kind == "eig":
+            lam, vecs = c.lambda_k, [c.v_k]
+        elif kind == "lin":
+            lam, vecs = 0j, [c.x_k]
+        else:
+            lam, vecs = c.sigma_k, [c.u_k, c.right_v_k]
+        rows.append({"id": c.id, "state": c.state.value, "stuck": c.stuck_counter, "retries": c.local_psi_retries_needed,
+                     "resets": c.num_resets, "w": c.w_k, "resid": c.residual_k, "alpha": c.alpha_local_step,
+                     "lam": lam, "vecs": vecs})
+    return rows
+
+
+def versions_match(rec):
+    import scipy
+    return rec["versions"]["numpy"] == np.__version__ and rec["versions"]["scipy"] == scipy.__version__
+
+
+# (the Hermitian scenarios are bit-exact too: eigh is computed once per matrix instead of once per
+# candidate, but it is the same LAPACK call on the same input, so (lambda, V) are identical)
+@pytest.mark.parametrize("name", ["eig16", "eig64", "eig48u", "lap8", "lin24", "lin32f", "svd5x4", "svd64",
+                                  "herm16", "herm64", "lap8h"])
+def test_host_logic_bit_exact_vs_reference_fixtures(name):
+    with open(os.path.join(GOLD, f"traj_{name}.json")) as f:
+        gold = json.load(f)
+    if not versions_match(gold):
+        pytest.skip("fixture captured under different numpy/scipy versions")
+    solver, spec = make_solver(name)
+    assert snapshot.digest_rows(rows_of(solver.candidates, spec["kind"])) == gold["init"]["digest"]
+    assert snapshot.rng_digest() == gold["init"]["rng"]
+    from adaptive_matrix_solver_amd.solver import SolutionCandidate
+    for it, g in enumerate(gold["iters"]):
+        solver._update_global_diagnostics(it + 1)
+        solver._adjust_global_strategy(it + 1)
+        steps = solver.step_population()
+        stepped = rows_of(solver.candidates, spec["kind"])
+        solver._manage_candidates(it + 1)
+        assert steps == g["steps"], f"iter {it}"
+        d = snapshot.digest_rows(stepped)
+        assert d["ints"] == g["digest_stepped"]["ints"], f"iter {it} bookkeeping"
+        assert snapshot.rng_digest() == g["rng"], f"iter {it} rng"
+        assert d["floats"] == g["digest_stepped"]["floats"], f"iter {it} scalars"
+        assert d["vecs"] == g["digest_stepped"]["vecs"], f"iter {it} vectors"
+        assert snapshot.digest_rows(rows_of(solver.candidates, spec["kind"])) == g["digest"], f"iter {it} managed"
+        got_glob = snapshot.globals_record(solver.landscape_energy, solver.avg_residual, solver.avg_stuckness,
+                                           solver.num_distinct_converged_solutions,
+                                           solver.problem_knowledge["numerical_stability_state"],
+                                           solver.problem_knowledge["local_solver_preference"], solver.strat_params)
+        assert got_glob == g["globals"], f"iter {it} globals"
+        assert SolutionCandidate._candidate_id_counter == g["next_id"]
+
+
+def test_fast_mode_keeps_stream_and_bookkeeping():
+    """pert_mode='none': the perturbation is dropped and the NumPy stream is advanced by the
+    MT19937 jump -- stream position and bookkeeping must still equal the reference's."""
+    with open(os.path.join(GOLD, "traj_eig64.json")) as f:
+        gold = json.load(f)
+    if not versions_match(gold):
+        pytest.skip("fixture captured under different numpy/scipy versions")
+    solver, spec = make_solver("eig64", pert_mode="none")
+    for it, g in enumerate(gold["iters"]):
+        solver._update_global_diagnostics(it + 1)
+        solver._adjust_global_strategy(it + 1)
+        solver.step_population()
+        stepped = rows_of(solver.candidates, spec["kind"])
+        solver._manage_candidates(it + 1)
+        assert snapshot.digest_rows(stepped)["ints"] == g["digest_stepped"]["ints"], f"iter {it}"
+        assert snapshot.rng_digest() == g["rng"], f"iter {it} rng"
+
+
+def test_nan_ladder_matches_reference():
+    from adaptive_matrix_solver_amd.engine import DeviceEngine
+    from adaptive_matrix_solver_amd.solver import ProblemType, SolutionCandidate
+    with open(os.path.join(GOLD, "nan_ladder.json")) as f:
+        gold = json.load(f)
+    n = gold["n"]
+    A = scenarios.ginibre(n, gold["matrix_seed"], 1.0)
+    A[tuple(gold["nan_at"])] = np.nan
+    np.random.seed(gold["seed"]); random.seed(gold["seed"]); SolutionCandidate._candidate_id_counter = 0
+    eng = DeviceEngine(ctx=FakeContext(), pert_mode="uniform", gmres_compat="scipy-legacy")
+    c = SolutionCandidate(A, ProblemType.EIGENVALUE, n, engine=eng)
+    strat = {"overall_psi_aggression_factor": 1.0, "max_psi_retries": 25, "current_convergence_threshold": 1e-8,
+             "convergence_tolerance": 1e-8}
+    know = {"local_solver_preference": "direct_solve", "is_sparse_problem": False, "is_hermitian": False}
+    for i, g in enumerate(gold["steps"]):
+        with np.errstate(all="ignore"):
+            c.update_solution_step(A, None, strat, know)
+        a = complex(c.alpha_local_step)
+        got = {"state": c.state.value, "stuck": c.stuck_counter, "retries": c.local_psi_retries_needed,
+               "resets": c.num_resets, "w": float(c.w_k).hex(), "alpha": [a.real.hex(), a.imag.hex()],
+               "resid_nan": bool(np.isnan(c.residual_k)), "hist_len": len(c.residual_history),
+               "rng": snapshot.rng_digest(), "mt_pos": int(np.random.get_state()[2])}
+        assert got == g, f"step {i}"
+
+
+def test_sparse_inputs_rejected_loudly():
+    import scipy.sparse as sp
+    from adaptive_matrix_solver_amd.solver import MAUS_Solver, ProblemType
+    with pytest.raises(NotImplementedError):
+        MAUS_Solver(sp.identity(8, format="csc"), ProblemType.EIGENVALUE)
+
+
+def test_mt19937_jump_equals_drawing():
+    from adaptive_matrix_solver_amd import _cabi
+    for seed, nwords, pre in [(1, 100, 0), (2, 4 * 64 * 64, 17), (3, 4 * 300 * 300, 623), (4, 4 * 1024 * 1024, 5)]:
+        np.random.seed(seed)
+        if pre:
+            np.random.rand(pre)
+        st = np.random.get_state()
+        key, pos = _cabi.mt19937_jump(st[1], st[2], nwords)
+        np.random.rand(nwords // 2)
+        st2 = np.random.get_state()
+        assert np.array_equal(key, st2[1]) and pos == st2[2]
