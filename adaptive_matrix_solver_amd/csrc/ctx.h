@@ -1,0 +1,89 @@
+// Internal definitions shared by capi.hip and gmres.hip (not part of the C ABI).
+#pragma once
+#include "common.h"
+#include "../../include/maus_hip.h"
+
+#include <string>
+#include <vector>
+
+// ---- kernels / drivers implemented in the other translation units ---------------------
+struct LuWs {
+    c128* H; long ldh; long strideH; int n; int npad; int G;
+    int* ipiv; int* info; int* flags;
+    hipStream_t st;
+    void (*tick)(void* ud, int klass, int phase, double flops, double bytes); void* ud;
+};
+void maus_lu_factor(const LuWs& w, int nbo);
+void maus_lu_backsolve(const LuWs& w, c128* Wpop, long ldw, const int* d_slots, c128* xout_dense);
+void maus_build_h(const LuWs& w, const c128* A, const c128* d_shift, const double* d_psi, int rhs_mode,
+                  const c128* X, long ldx, const int* d_slots, const c128* bvec, int pert_mode, const double* d_U);
+void maus_load_h(const LuWs& w, const c128* d_Ain, const c128* d_bin);
+int maus_lu_max_npad();
+void maus_zgemm_launch_idx(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,
+                           const c128* B, long ldb, long sB, c128* C, long ldc, long sC,
+                           double alpha, int beta, int batch, int blay, bool conja, bool conjb,
+                           const int* a_rows, const int* c_rows);
+void maus_launch_rayleigh_dots(hipStream_t st, const c128* X, const c128* Y, long ld, const int* slots, int count, int n, c128* num, c128* den);
+void maus_launch_relax(hipStream_t st, c128* X, const c128* W, long ld, const int* slots, int count, int n, const c128* alpha, int normalise, double* norm_out);
+void maus_launch_residual(hipStream_t st, int kind, const c128* X, const c128* Y, long ld, const int* slots, int count, int n,
+                          const c128* lam, const c128* bvec, double* resid, int* finite);
+void maus_launch_svd_resid(hipStream_t st, const c128* Yv, const c128* Uv, long ld, const int* slots, int count, int n,
+                           const c128* sigma, double* out, int accumulate, int* finite);
+void maus_launch_norm_scale(hipStream_t st, const c128* S, c128* D, long ld, const int* slots, int count, int n, double* norm_out, int stride_out, int off_out);
+void maus_launch_norm(hipStream_t st, const c128* S, long ld, const int* slots, int count, int n, double* norm_out, int stride_out, int off_out);
+void maus_launch_herm_pick(hipStream_t st, const c128* S, long lds_, c128* X, long ldx, const int* slots, int count, const c128* V, int n, int* idx_out, double* norm_out);
+int maus_gmres_run(maus_ctx* ctx, const int* slots, int count, const double* shift, const double* psi, int rhs_mode,
+                   const int32_t* use_jacobi, double rtol, int restart, int maxiter, int32_t* info_out, int32_t* inner_out, int32_t* status);
+int maus_jacobi_check_run(maus_ctx* ctx, int count, const double* shift, const double* psi, int32_t* ok);
+
+// ---- context ---------------------------------------------------------------------------
+struct ProfRec { int klass; hipEvent_t e0, e1; double flops, bytes; };
+
+struct maus_ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::string err;
+    c128* A = nullptr; int rows = 0, cols = 0;      // problem matrix
+    c128* b = nullptr; int bn = 0;                  // rhs
+    c128* V = nullptr; int vn = 0;                  // eigenvectors (Hermitian shortcut)
+    int cap = 0; long ldp = 0;                      // population
+    c128 *X = nullptr, *U = nullptr, *W = nullptr, *Y = nullptr;
+    // per-call scalar staging (device), sized for `scal_cap` candidates
+    int scal_cap = 0;
+    int *d_slots = nullptr, *d_i1 = nullptr, *d_i2 = nullptr;
+    c128 *d_c1 = nullptr, *d_c2 = nullptr;
+    double *d_r1 = nullptr, *d_r2 = nullptr;
+    // LU workspace
+    c128* H = nullptr; size_t Hbytes = 0; int Hg = 0; int Hnpad = 0;
+    int *ipiv = nullptr, *info = nullptr, *flags = nullptr;
+    double* Upert = nullptr; size_t Ubytes = 0;
+    // generic scratch (host-GEMM / host-LU test entry points, GMRES)
+    void* scratch = nullptr; size_t scratch_bytes = 0;
+    // measurement
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool prof_on = false;
+    std::vector<ProfRec> pending;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t cur0 = nullptr;
+    int launches[KC_COUNT] = {0}; double ms[KC_COUNT] = {0}, flops[KC_COUNT] = {0}, bytes[KC_COUNT] = {0};
+};
+
+extern thread_local std::string g_err;
+
+#define FAIL(ctx, msg) do { (ctx)->err = (msg); return -1; } while (0)
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+        char buf_[512]; snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+        (ctx)->err = buf_; return -1; } } while (0)
+
+
+int ensure_scalars(maus_ctx* c, int count);
+int ensure_scratch(maus_ctx* c, size_t bytes);
+int check_slots(maus_ctx* c, const int* slots, int count);
+int upload_slots(maus_ctx* c, const int* slots, int count);
+void prof_tick(void* ud, int klass, int phase, double flops, double bytes);
+
+struct ProfScope {
+    maus_ctx* c; int k; double f, b;
+    ProfScope(maus_ctx* c_, int k_, double f_ = 0, double b_ = 0) : c(c_), k(k_), f(f_), b(b_) { prof_tick(c, k, 0, 0, 0); }
+    ~ProfScope() { prof_tick(c, k, 1, f, b); }
+};

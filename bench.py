@@ -83,7 +83,8 @@ def main():
     comm = None
     if world > 1:
         from adaptive_matrix_solver_amd import dist as mdist
-        comm = mdist.init_from_env("nccl")
+        # nccl == RCCL over xGMI; MAUS_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsal
+        comm = mdist.init_from_env(os.environ.get("MAUS_DIST_BACKEND", "nccl"))
 
     import scenarios
     from adaptive_matrix_solver_amd.solver import MAUS_Solver, ProblemType, SolutionCandidate
@@ -93,7 +94,8 @@ def main():
     np.random.seed(1234); random.seed(1234); SolutionCandidate._candidate_id_counter = 0
     t_build = time.perf_counter()
     solver = MAUS_Solver(A, ProblemType.EIGENVALUE, initial_num_candidates=P, global_convergence_tol=1e-8,
-                         device=local_rank, pert_mode="auto", comm=comm, quiet=True, record_history=False)
+                         device=local_rank if os.environ.get("MAUS_DIST_BACKEND", "nccl") == "nccl" else 0,
+                         pert_mode="auto", comm=comm, quiet=True, record_history=False)
     t_build = time.perf_counter() - t_build
     ctx = solver.engine.ctx
     info = ctx.device_info()
@@ -101,8 +103,9 @@ def main():
     def sync_all():
         ctx.sync()
         if comm is not None:
-            import torch
-            torch.cuda.synchronize()
+            if comm.on_device:
+                import torch
+                torch.cuda.synchronize()
             comm.barrier()
 
     it = 0
@@ -120,7 +123,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if comm is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=comm.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm.device if comm.on_device else "cpu")
         comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = ctx.profile_read()
