@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=4096, help="matrix order (default: the metric's 4096)")
+    ap.add_argument("--size", dest="n", type=int, default=4096, help="matrix order (default: the metric's 4096)")
     ap.add_argument("--pop", type=int, default=256, help="initial_num_candidates (default: the metric's 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
