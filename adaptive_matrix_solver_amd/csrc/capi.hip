@@ -54,8 +54,9 @@ void prof_tick(void* ud, int klass, int phase, double flops, double bytes) {
     maus_ctx* c = (maus_ctx*)ud;
     if (!c->prof_on) return;
     auto get = [&]() { hipEvent_t e; if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
-    if (phase == 0) { c->cur0 = get(); (void)hipEventRecord(c->cur0, c->st); }
-    else { hipEvent_t e1 = get(); (void)hipEventRecord(e1, c->st); c->pending.push_back({klass, c->cur0, e1, flops, bytes}); c->cur0 = nullptr; }
+    hipStream_t st = c->prof_st ? c->prof_st : c->st;
+    if (phase == 0) { c->cur0 = get(); (void)hipEventRecord(c->cur0, st); }
+    else { hipEvent_t e1 = get(); (void)hipEventRecord(e1, st); c->pending.push_back({klass, c->cur0, e1, flops, bytes}); c->cur0 = nullptr; }
 }
 
 static void prof_resolve(maus_ctx* c) {
@@ -97,6 +98,9 @@ int maus_ctx_destroy(maus_ctx* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& r : c->pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
+    for (auto st : c->lu_st) (void)hipStreamDestroy(st);
+    for (auto e : c->lu_done) (void)hipEventDestroy(e);
+    if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     (void)hipStreamDestroy(c->st);
@@ -274,6 +278,19 @@ static LuWs make_ws(maus_ctx* c, int n, int G) {
     return w;
 }
 
+static int lu_stream_count() { const char* e = getenv("MAUS_LU_STREAMS"); int v = e ? atoi(e) : 1; return std::max(1, std::min(8, v)); }
+
+static int ensure_lu_streams(maus_ctx* c, int n) {
+    if (!c->ev_stage) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
+    while ((int)c->lu_st.size() < n) {
+        hipStream_t s; hipEvent_t e;
+        HIPCHK(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->lu_st.push_back(s); c->lu_done.push_back(e);
+    }
+    return 0;
+}
+
 static int lu_nbo() { const char* e = getenv("MAUS_LU_NBO"); int v = e ? atoi(e) : 256; if (v < 32) v = 32; return (v / 32) * 32; }
 
 static void finish_status(int G, const int* info, const int* flags, int32_t* status) {
@@ -300,10 +317,11 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
     // balanced chunks (271 candidates in a 256-matrix workspace run as 136 + 135, not 256 + 15)
     const int nchunks = (count + c->Hg - 1) / c->Hg;
     const int Gmax = (count + nchunks - 1) / nchunks;
+    const int nst = lu_stream_count();
+    if (ensure_lu_streams(c, nst)) return -1;
     std::vector<int> h_info(Gmax), h_flags(Gmax);
     for (int off = 0; off < count; off += Gmax) {
         const int G = std::min(Gmax, count - off);
-        LuWs w = make_ws(c, n, G);
         HIPCHK(c, hipMemcpyAsync(c->d_slots, slots + off, sizeof(int) * G, hipMemcpyHostToDevice, c->st));
         HIPCHK(c, hipMemcpyAsync(c->d_c1, shift + 2 * (size_t)off, sizeof(c128) * G, hipMemcpyHostToDevice, c->st));
         HIPCHK(c, hipMemcpyAsync(c->d_r1, psi + off, sizeof(double) * G, hipMemcpyHostToDevice, c->st));
@@ -316,9 +334,24 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             HIPCHK(c, hipMemcpyAsync(c->Upert, (const double*)pert_data + 2 * (size_t)n * n * off, ub, hipMemcpyHostToDevice, c->st));
             dU = c->Upert;
         }
-        maus_build_h(w, c->A, c->d_c1, c->d_r1, rhs_mode, c->X, c->ldp, c->d_slots, c->b, pert_mode, dU);
-        maus_lu_factor(w, lu_nbo());
-        maus_lu_backsolve(w, c->W, c->ldp, c->d_slots, nullptr);
+        // sub-batches on their own streams (at least 8 matrices each)
+        const int S = std::max(1, std::min(nst, G / 8));
+        if (S > 1) HIPCHK(c, hipEventRecord(c->ev_stage, c->st));
+        for (int sb = 0; sb < S; ++sb) {
+            const int lo = (int)((long)G * sb / S), hi = (int)((long)G * (sb + 1) / S), g = hi - lo;
+            if (g <= 0) continue;
+            hipStream_t st = (S == 1) ? c->st : c->lu_st[sb];
+            if (S > 1) HIPCHK(c, hipStreamWaitEvent(st, c->ev_stage, 0));
+            LuWs w = make_ws(c, n, g);
+            w.H += (long)lo * w.strideH; w.ipiv += (long)lo * w.npad; w.info += lo; w.flags += lo; w.st = st;
+            c->prof_st = st;
+            maus_build_h(w, c->A, c->d_c1 + lo, c->d_r1 + lo, rhs_mode, c->X, c->ldp, c->d_slots + lo, c->b, pert_mode,
+                         dU ? dU + 2 * (size_t)n * n * lo : nullptr);
+            maus_lu_factor(w, lu_nbo());
+            maus_lu_backsolve(w, c->W, c->ldp, c->d_slots + lo, nullptr);
+            if (S > 1) { HIPCHK(c, hipEventRecord(c->lu_done[sb], st)); HIPCHK(c, hipStreamWaitEvent(c->st, c->lu_done[sb], 0)); }
+        }
+        c->prof_st = nullptr;
         HIPCHK(c, hipMemcpyAsync(h_info.data(), c->info, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipMemcpyAsync(h_flags.data(), c->flags, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
@@ -459,6 +492,37 @@ int maus_zgemm_host(maus_ctx* c, int M, int N, int K, const double* A, const dou
       maus_zgemm_launch_idx(c->st, M, N, K, dA, K, 0, dB, b_layout ? K : N, 0, dC, N, 0, alpha, beta, 1, b_layout, conj_a != 0, conj_b != 0, nullptr, nullptr); }
     HIPCHK(c, hipMemcpyAsync(C, dC, sizeof(c128) * ec, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+__global__ void fill_rand_kernel(double* p, size_t n, unsigned seed) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) { unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; p[i] = (double)(x & 0xffffff) / 16777216.0 - 0.5; }
+}
+
+int maus_zgemm_bench(maus_ctx* c, int M, int N, int K, int ld, int batch, int iters, float* ms_out) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || iters <= 0 || ld < std::max(N, K) + K) FAIL(c, "maus_zgemm_bench: bad sizes");
+    // one array per matrix with rows = max(M, K) + K, laid out like the LU workspace: A = rows K.., cols 0..K ;
+    // B = rows 0..K, cols K.. ; C = rows K.., cols K..
+    const long rows = (long)M + K;
+    const size_t per = (size_t)rows * ld;
+    if (ensure_scratch(c, sizeof(c128) * per * batch)) return -1;
+    c128* base = (c128*)c->scratch;
+    if (getenv("MAUS_BENCH_ZERO")) { HIPCHK(c, hipMemsetAsync(base, 0, sizeof(c128) * per * batch, c->st)); }   // DVFS check
+    else hipLaunchKernelGGL(fill_rand_kernel, dim3(2048), dim3(256), 0, c->st, (double*)base, per * batch * 2, 12345u);
+    auto launch = [&]() {
+        maus_zgemm_launch_idx(c->st, M, N, K, base + (size_t)K * ld, ld, (long)per, base + K, ld, (long)per,
+                              base + (size_t)K * ld + K, ld, (long)per, -1.0, 1, batch, 0, false, false, nullptr, nullptr);
+    };
+    launch();
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipEventRecord(c->t0, c->st));
+    for (int i = 0; i < iters; ++i) launch();
+    HIPCHK(c, hipEventRecord(c->t1, c->st));
+    HIPCHK(c, hipEventSynchronize(c->t1));
+    float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, c->t0, c->t1));
+    *ms_out = ms / iters;
     HIPCHK(c, hipGetLastError());
     return 0;
 }

@@ -57,6 +57,10 @@ struct maus_ctx {
     c128* H = nullptr; size_t Hbytes = 0; int Hg = 0; int Hnpad = 0;
     int *ipiv = nullptr, *info = nullptr, *flags = nullptr;
     double* Upert = nullptr; size_t Ubytes = 0;
+    // sub-batch streams: bandwidth-bound phases (panel, swaps, trsm) of one sub-batch overlap the
+    // MFMA-bound trailing updates of another
+    std::vector<hipStream_t> lu_st; std::vector<hipEvent_t> lu_done; hipEvent_t ev_stage = nullptr;
+    hipStream_t prof_st = nullptr;
     // generic scratch (host-GEMM / host-LU test entry points, GMRES)
     void* scratch = nullptr; size_t scratch_bytes = 0;
     // measurement

@@ -253,21 +253,40 @@ lu_panel_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
                 for (int i = 0; i < PW; ++i) { P[(long)(c0 + i) * ld + cc] = u[i]; s_U[i][tid] = u[i]; }
             }
             __syncthreads();
-            // (e) rank-4 update of the trailing panel columns for rows below the sub-block
+            // (e) rank-4 update of the trailing panel columns for the rows below the sub-block, on the
+            //     matrix cores: C[16x16] -= L[16x4] * U12[4x16] is one K=4 step of v_mfma_f64_16x16x4
+            //     (x4 for the complex product).  Tiles are loaded/stored a[row=l&15][k=l>>4],
+            //     c[r] = C[row=(l>>4)+4r][col=l&15]: 256 contiguous bytes per row and instruction,
+            //     instead of the one-row-per-lane pattern of the register sub-block.
+            {
+                const int rmin = c0 + PW;
+                const int ntile = (m + 15) >> 4;
+                for (int t = (rmin >> 4) + wave; t < ntile; t += PT / 64) {
+                    const int arow = 16 * t + (lane & 15);
+                    c128 av = cmake(0.0, 0.0);
+                    if (arow < m) av = P[(long)arow * ld + c0 + (lane >> 4)];
+                    for (int j = rmin >> 4; j < NBP / 16; ++j) {
+                        const int col = 16 * j + (lane & 15);
+                        const int cc = col - rmin;
+                        c128 bv = cmake(0.0, 0.0);
+                        if (cc >= 0) bv = s_U[lane >> 4][cc];
+                        d4 cre, cim;
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = tid + k * PT;
-                if (r < m && r >= c0 + PW) {
-                    c128* row = P + (long)r * ld + c0 + PW;
-                    for (int cc = 0; cc < nt; cc += 4) {
-                        c128 x0 = row[cc], x1 = row[cc + 1], x2 = row[cc + 2], x3 = row[cc + 3];
-#pragma unroll
-                        for (int q = 0; q < PW; ++q) {
-                            const c128 l = R[k][q];
-                            cfms(x0, l, s_U[q][cc]); cfms(x1, l, s_U[q][cc + 1]);
-                            cfms(x2, l, s_U[q][cc + 2]); cfms(x3, l, s_U[q][cc + 3]);
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * t + (lane >> 4) + 4 * r;
+                            c128 cv = cmake(0.0, 0.0);
+                            if (row < m) cv = P[(long)row * ld + col];
+                            cre[r] = cv.x; cim[r] = cv.y;
                         }
-                        row[cc] = x0; row[cc + 1] = x1; row[cc + 2] = x2; row[cc + 3] = x3;
+                        cre = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, cre, 0, 0, 1);   // -= Lre*Ure
+                        cim = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.y, cim, 0, 0, 1);   // -= Lre*Uim
+                        cre = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, cre, 0, 0, 0);   // += Lim*Uim
+                        cim = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.x, cim, 0, 0, 1);   // -= Lim*Ure
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * t + (lane >> 4) + 4 * r;
+                            if (row < m && row >= rmin && cc >= 0) P[(long)row * ld + col] = cmake(cre[r], cim[r]);
+                        }
                     }
                 }
             }

@@ -18,16 +18,17 @@
 // Tiling: BM x BN block tile, BK = 16, tiles staged through LDS as [k][m] / [k][n]
 // (k-major, +1 element row padding) so every fragment is one ds_read_b128 of an
 // interleaved (re,im) pair; the next K-tile is prefetched into registers while the
-// current one feeds the MFMAs.  >= 2 waves per SIMD are needed to keep the fp64
-// matrix pipe issuing back to back (probe: 35 TF at 1 wave/SIMD, 47 TF at 2).
+// current one feeds the MFMAs.  The fp64 matrix pipe sustains 77.9 TFLOP/s with VGPR
+// accumulators (tools/probe_mfma_f64_v2; AGPR accumulators run at less than half of that),
+// but only if independent waves fill each other's waits: see the launcher for the measured
+// tile / occupancy choice.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int BK = 16;
-
-template <int BM, int BN, int WM, int WN, int BLAY, bool CONJA, bool CONJB>
-__global__ void __launch_bounds__(64 * WM * WN)
+template <int BM, int BN, int BK, int WM, int WN, int BLAY, bool CONJA, bool CONJB, bool M3, bool PIPE, int MINW>
+__global__ void __launch_bounds__(64 * WM * WN, MINW)
 zgemm_kernel(int M, int N, int K,
              const c128* __restrict__ Ag, long lda, long strideA,
              const c128* __restrict__ Bg, long ldb, long strideB,
@@ -42,9 +43,8 @@ zgemm_kernel(int M, int N, int K,
     constexpr int A_PER = BM * BK / NT, B_PER = BN * BK / NT;
     static_assert(A_PER * NT == BM * BK && B_PER * NT == BN * BK, "tile/threads mismatch");
 
-    __shared__ c128 smem[BK * LDA_S + BK * LDB_S];
-    c128* As = smem;
-    c128* Bs = smem + BK * LDA_S;
+    constexpr int TILE_S = BK * LDA_S + BK * LDB_S;          // one staged K-tile (A then B), elements
+    __shared__ c128 smem[(PIPE ? 2 : 1) * TILE_S];            // PIPE: double buffered, one barrier per K-tile
 
     // XCD-aware block -> tile map: blocks b and b+8 share an XCD (L2); give each XCD a
     // contiguous run of tiles so neighbouring tiles (same A row-panel) hit one L2.
@@ -63,51 +63,62 @@ zgemm_kernel(int M, int N, int K,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
 
-    d4 cre[MB][NB], cim[MB][NB];
+    // 4M: cre = Re, cim = Im.  3M (Karatsuba): cre = sum Are*Bre, cim = sum Aim*Bim, c3 = sum (Are+Aim)(Bre+Bim);
+    // Re = cre - cim, Im = c3 - cre - cim  (3 MFMAs per block and k-step instead of 4)
+    d4 cre[MB][NB], cim[MB][NB], c3[M3 ? MB : 1][M3 ? NB : 1];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { cre[i][j] = (d4){0, 0, 0, 0}; cim[i][j] = (d4){0, 0, 0, 0}; }
+        for (int j = 0; j < NB; ++j) {
+            cre[i][j] = (d4){0, 0, 0, 0}; cim[i][j] = (d4){0, 0, 0, 0};
+            if (M3) c3[i][j] = (d4){0, 0, 0, 0};
+        }
 
     c128 ra[A_PER], rb[B_PER];
 
+    // Branch-free tile loads: per-thread base pointers are computed once (row / column indices
+    // clamped into range -- out-of-range rows and columns only feed C entries that are never
+    // stored), so a K-tile costs one pointer add per element inside the loop.  Only when K is not
+    // a multiple of BK (KEDGE) is the k index clamped and the value zeroed by a select.
+    const bool KEDGE = (K % BK) != 0;
+    const c128* pa[A_PER];
+    const c128* pb[B_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        int r = tid / BK + i * (NT / BK);
+        int gm = min(m0 + r, M - 1);
+        pa[i] = A + (long)(a_rows ? a_rows[gm] : gm) * lda;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        if (BLAY == 0) { int gn = min(n0 + tid % BN, N - 1); pb[i] = B + gn; }
+        else { int gn = min(n0 + tid / BK + i * (NT / BK), N - 1); pb[i] = B + (long)gn * ldb; }
+    }
     auto load_tiles = [&](int k0) {
-        // A tile: [BM rows][BK k], k contiguous in memory
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            int k = tid & (BK - 1), r = (tid >> 4) + i * (NT / BK);
-            int gm = m0 + r, gk = k0 + k;
-            c128 v = cmake(0.0, 0.0);
-            if (gm < M && gk < K) v = A[(long)(a_rows ? a_rows[gm] : gm) * lda + gk];
+            int gk = k0 + (tid & (BK - 1));
+            c128 v = pa[i][KEDGE ? min(gk, K - 1) : gk];
+            if (KEDGE && gk >= K) v = cmake(0.0, 0.0);
             if (CONJA) v.y = -v.y;
             ra[i] = v;
         }
-        if (BLAY == 0) {   // B[k][n], n contiguous
 #pragma unroll
-            for (int i = 0; i < B_PER; ++i) {
-                int n = tid % BN, k = tid / BN + i * (NT / BN);
-                int gn = n0 + n, gk = k0 + k;
-                c128 v = cmake(0.0, 0.0);
-                if (gn < N && gk < K) v = B[(long)gk * ldb + gn];
-                if (CONJB) v.y = -v.y;
-                rb[i] = v;
-            }
-        } else {           // B[n][k], k contiguous
-#pragma unroll
-            for (int i = 0; i < B_PER; ++i) {
-                int k = tid & (BK - 1), r = (tid >> 4) + i * (NT / BK);
-                int gn = n0 + r, gk = k0 + k;
-                c128 v = cmake(0.0, 0.0);
-                if (gn < N && gk < K) v = B[(long)gn * ldb + gk];
-                if (CONJB) v.y = -v.y;
-                rb[i] = v;
-            }
+        for (int i = 0; i < B_PER; ++i) {
+            int gk = (BLAY == 0) ? k0 + tid / BN + i * (NT / BN) : k0 + (tid & (BK - 1));
+            int ck = KEDGE ? min(gk, K - 1) : gk;
+            c128 v = (BLAY == 0) ? pb[i][(long)ck * ldb] : pb[i][ck];
+            if (KEDGE && gk >= K) v = cmake(0.0, 0.0);
+            if (CONJB) v.y = -v.y;
+            rb[i] = v;
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int buf) {
+        c128* As = smem + buf * TILE_S;
+        c128* Bs = As + BK * LDA_S;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            int k = tid & (BK - 1), r = (tid >> 4) + i * (NT / BK);
+            int k = tid & (BK - 1), r = tid / BK + i * (NT / BK);
             As[k * LDA_S + r] = ra[i];
         }
         if (BLAY == 0) {
@@ -119,75 +130,141 @@ zgemm_kernel(int M, int N, int K,
         } else {
 #pragma unroll
             for (int i = 0; i < B_PER; ++i) {
-                int k = tid & (BK - 1), r = (tid >> 4) + i * (NT / BK);
+                int k = tid & (BK - 1), r = tid / BK + i * (NT / BK);
                 Bs[k * LDB_S + r] = rb[i];
             }
         }
     };
 
+    // ---- software-pipelined main loop ---------------------------------------------------------
+    // LDS buffer t&1 holds K-tile t.  While the MFMAs of tile t run: the fragments of the next
+    // k-step are already in flight (register double buffer), tile t+1 moves registers -> LDS, and
+    // tile t+2 is requested from global memory.  One barrier per K-tile.
     const int nkt = (K + BK - 1) / BK;
-    load_tiles(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();            // everyone finished reading the previous tile
-        store_tiles();
-        __syncthreads();
-        if (kt + 1 < nkt) load_tiles((kt + 1) * BK);   // in flight during the MFMAs below
+    constexpr int KSTEPS = BK / 4;
+    c128 fa[2][MB], fb[2][NB];
+    auto read_frags = [&](int buf, int kk, int slot) {
+        const c128* As = smem + buf * TILE_S;
+        const c128* Bs = As + BK * LDA_S;
+        const int krow = kk * 4 + (lane >> 4);
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            const int krow = kk * 4 + (lane >> 4);
-            c128 a[MB], b[NB];
+        for (int i = 0; i < MB; ++i) fa[slot][i] = As[krow * LDA_S + wm * WTM + i * 16 + (lane & 15)];
 #pragma unroll
-            for (int i = 0; i < MB; ++i) a[i] = As[krow * LDA_S + wm * WTM + i * 16 + (lane & 15)];
+        for (int j = 0; j < NB; ++j) fb[slot][j] = Bs[krow * LDB_S + wn * WTN + j * 16 + (lane & 15)];
+    };
+    auto mfma_group = [&](int slot) {
+        if (M3) {
+            double sa[MB], sb[NB];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) b[j] = Bs[krow * LDB_S + wn * WTN + j * 16 + (lane & 15)];
+            for (int i = 0; i < MB; ++i) sa[i] = fa[slot][i].x + fa[slot][i].y;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) sb[j] = fb[slot][j].x + fb[slot][j].y;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    cre[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][i].x, fb[slot][j].x, cre[i][j], 0, 0, 0);
+                    cim[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][i].y, fb[slot][j].y, cim[i][j], 0, 0, 0);
+                    c3[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[i], sb[j], c3[i][j], 0, 0, 0);
+                }
+        } else {
             // first products of every block (independent accumulators back to back) ...
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    cre[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, cre[i][j], 0, 0, 0);
-                    cim[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].y, cim[i][j], 0, 0, 0);
+                    cre[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][i].x, fb[slot][j].x, cre[i][j], 0, 0, 0);
+                    cim[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][i].x, fb[slot][j].y, cim[i][j], 0, 0, 0);
                 }
             // ... then the second products (BLGP=1: negate A -> Cre -= Aim*Bim)
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    cre[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, cre[i][j], 0, 0, 1);
-                    cim[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].x, cim[i][j], 0, 0, 0);
+                    cre[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][i].y, fb[slot][j].y, cre[i][j], 0, 0, 1);
+                    cim[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][i].y, fb[slot][j].x, cim[i][j], 0, 0, 0);
                 }
+        }
+    };
+
+    if (PIPE) {
+        load_tiles(0);
+        store_tiles(0);
+        if (nkt > 1) load_tiles(BK);                         // tile 1 in flight
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = kt & 1;
+            read_frags(buf, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                if (kk + 1 < KSTEPS) read_frags(buf, kk + 1, (kk + 1) & 1);     // next k-step's fragments
+                if (kk == 0 && kt + 1 < nkt) store_tiles(buf ^ 1);               // tile t+1: registers -> LDS
+                if (kk == 0 && kt + 2 < nkt) load_tiles((kt + 2) * BK);          // tile t+2: global -> registers
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(kk & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+    } else {
+        // lean form for >= 2 workgroups per CU: one LDS buffer, two barriers per K-tile; the bubbles of
+        // one workgroup are filled by the independent waves of the others
+        load_tiles(0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            __syncthreads();
+            store_tiles(0);
+            __syncthreads();
+            if (kt + 1 < nkt) load_tiles((kt + 1) * BK);
+            read_frags(0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                if (kk + 1 < KSTEPS) read_frags(0, kk + 1, (kk + 1) & 1);
+                mfma_group(kk & 1);
+            }
         }
     }
 
-    // epilogue: d[r] -> row (lane>>4) + 4r, col lane&15 of each 16x16 block
+    // epilogue: d[r] -> row (lane>>4) + 4r, col lane&15 of each 16x16 block; per block the four old
+    // C values are fetched together, then combined and stored
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int gn = n0 + wn * WTN + j * 16 + (lane & 15);
+            c128 cold[4];
+            long off[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm * WTM + i * 16 + (lane >> 4) + 4 * r;
+                const int cm = min(gm, M - 1), cn = min(gn, N - 1);
+                off[r] = (long)(c_rows ? c_rows[cm] : cm) * ldc + cn;
+                cold[r] = cmake(0.0, 0.0);
+                if (beta) cold[r] = C[off[r]];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gm = m0 + wm * WTM + i * 16 + (lane >> 4) + 4 * r;
                 if (gm < M && gn < N) {
-                    c128* p = C + (long)(c_rows ? c_rows[gm] : gm) * ldc + gn;
-                    c128 v = cmake(alpha * cre[i][j][r], alpha * cim[i][j][r]);
-                    if (beta) { c128 o = *p; v.x += o.x; v.y += o.y; }
-                    *p = v;
+                    double vr = cre[i][j][r], vi = cim[i][j][r];
+                    if (M3) { const double p1 = vr, p2 = vi; vr = p1 - p2; vi = (c3[i][j][r] - p1) - p2; }
+                    C[off[r]] = cmake(alpha * vr + cold[r].x, alpha * vi + cold[r].y);
                 }
             }
         }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, bool PIPE, int MINW>
 void launch_cfg(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA, const c128* B, long ldb, long sB,
                 c128* C, long ldc, long sC, double alpha, int beta, int batch, int blay, bool conja, bool conjb,
-                const int* a_rows, const int* c_rows)
+                const int* a_rows, const int* c_rows, bool m3)
 {
     int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     int nwg = tiles_m * tiles_n;
     dim3 grid(nwg, batch), block(64 * WM * WN);
-#define LAUNCH(BL, CA, CB) hipLaunchKernelGGL((zgemm_kernel<BM, BN, WM, WN, BL, CA, CB>), grid, block, 0, st, \
-        M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows)
+#define LAUNCH(BL, CA, CB) do { if (m3) hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WM, WN, BL, CA, CB, true, PIPE, MINW>), grid, block, 0, st, \
+        M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows); \
+      else hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WM, WN, BL, CA, CB, false, PIPE, MINW>), grid, block, 0, st, \
+        M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows); } while (0)
     if (blay == 0) {
         if (!conja && !conjb) LAUNCH(0, false, false);
         else if (!conja && conjb) LAUNCH(0, false, true);
@@ -213,13 +290,21 @@ void maus_zgemm_launch_idx(hipStream_t st, int M, int N, int K, const c128* A, l
                            const int* a_rows, const int* c_rows)
 {
     if (M <= 0 || N <= 0 || batch <= 0) return;
+    // MAUS_GEMM_3M=1: Karatsuba complex product (3 real MFMA products instead of 4; normwise-stable,
+    // Higham 1992).  Off by default: the 4M form has the rounding structure of a scalar FMA chain.
+    static const bool m3 = [] { const char* e = getenv("MAUS_GEMM_3M"); return e && atoi(e) != 0; }();
     // 128x64 tiles (8 waves, 2/SIMD at one block per CU) once the problem fills the chip with
     // them; 64x64 (4 waves, two blocks per CU) otherwise.
-    long t128 = (long)((M + 127) / 128) * ((N + 63) / 64) * batch;
-    if (M >= 128 && t128 >= 512)
-        launch_cfg<128, 64, 4, 2>(st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, batch, blay, conja, conjb, a_rows, c_rows);
-    else
-        launch_cfg<64, 64, 2, 2>(st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, batch, blay, conja, conjb, a_rows, c_rows);
+    static const int cfg = [] { const char* e = getenv("MAUS_GEMM_CFG"); return e ? atoi(e) : 0; }();
+#define ARGS st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, batch, blay, conja, conjb, a_rows, c_rows, m3
+    // Default: 64x64 tiles, 4 waves per workgroup, <= 128 VGPRs and 33 KB of LDS so that FOUR independent
+    // workgroups share a CU (4 waves per SIMD).  Measured on MI355X (tools/gemm_sweep*.py, K=256, 136
+    // matrices): 66 TFLOP/s, against 50-55 for every one-workgroup-per-CU variant (128x64 / 128x128
+    // tiles, BK 16/32, with or without the software-pipelined loop): with both waves of a SIMD in
+    // the same workgroup they run in lockstep and every wait or barrier of one is a bubble for both.
+    if (cfg == 1 && M >= 128) launch_cfg<128, 64, 16, 4, 2, true, 2>(ARGS);     // reference: pipelined, 1 WG/CU
+    else launch_cfg<64, 64, 16, 2, 2, false, 4>(ARGS);
+#undef ARGS
 }
 
 void maus_zgemm_launch(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,

@@ -489,16 +489,20 @@ class DeviceEngine:
             # --- RNG replay + bookkeeping for the accepted candidates, in list order ---
             if pert == PERT_UNIFORM:
                 np.random.set_state(rng_after[nvalid - 1] if nvalid > 0 else rng_start)
+            pending_words = 0          # E3 consumption not yet applied to the stream (one jump per run)
             for k in range(nvalid):
                 c = run[k]
                 if pert != PERT_UNIFORM:
-                    _advance_numpy_stream(per_cand_words)               # E3
+                    pending_words += per_cand_words                     # E3
                 c.local_psi_retries_needed = 0                          # attempts == 0 (AMS:278)
                 c._invalidate()
                 if is_eig and e4 is not None and (k == e4 or (pert != PERT_UNIFORM and not (nrm[k] > 1e-10))):
+                    _advance_numpy_stream(pending_words)
+                    pending_words = 0
                     c.v_k = (np.random.rand(n) + 1j * np.random.rand(n)) / np.sqrt(n)     # E4 (AMS:283)
                     c._push(force=True)
                 c.stuck_counter = max(0, c.stuck_counter - 1)           # AMS:286
+            _advance_numpy_stream(pending_words)
             if pert == PERT_UNIFORM and nvalid < nb:
                 for c in run[nvalid:nb]:                                # speculative relax undone
                     c._restore_device()

@@ -59,6 +59,38 @@ __global__ void __launch_bounds__(256) k_rate_clk(double* out, unsigned long lon
     if (l == 0) { clk[blockIdx.x * 2] = t1 - t0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
 }
 
+// co-execution: in each block of 8 waves (2 per SIMD) waves 0-3 issue MFMA f64, waves 4-7 VALU f64 FMA
+__global__ void __launch_bounds__(512) k_coexec(double* out, int iters_mfma, int iters_valu, double seed) {
+    int l = threadIdx.x;
+    if ((l >> 8) == 0) {
+        double a = seed + l * 1e-3, b = seed - l * 1e-3;
+        d4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int it = 0; it < iters_mfma; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        }
+        double s = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+        out[blockIdx.x * blockDim.x + l] = s;
+    } else {
+        double x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = seed + i + l * 1e-3;
+        double m = 1.0000001, c = 1e-9;
+        for (int it = 0; it < iters_valu; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = fma(x[i], m, c);
+        }
+        double s = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += x[i];
+        out[blockIdx.x * blockDim.x + l] = s;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_valu(double* out, int iters, double seed) {
     int l = threadIdx.x;
     double x[8];
@@ -153,6 +185,16 @@ int main() {
             CK(hipMemcpy(hc.data(), dClk, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost));
             double cyc = 0, rt = 0; for (int i = 0; i < blocks; ++i) { cyc += hc[2 * i]; rt += hc[2 * i + 1]; }
             printf("    in-kernel clock = %.3f GHz; shader cycles per MFMA per wave = %.1f\n", cyc / rt * 0.1, cyc / blocks / (4.0 * iters));
+        }
+    }
+    {
+        // 1 MFMA wave + 1 VALU wave per SIMD; iterations balanced so both halves run about equally long
+        for (int ratio : {0, 8, 16, 24}) {
+            int im = 20000, iv = im * ratio;
+            char nm[128];
+            snprintf(nm, sizeof nm, "coexec: MFMA x4 + VALU (%d fma-iters per mfma-iter)", ratio);
+            double fl = (2.0 * 16 * 16 * 4 * 4 * im * 4.0 + 2.0 * 8 * (double)iv * 256.0) * cus;
+            time_it([&] { hipLaunchKernelGGL(k_coexec, dim3(cus), dim3(512), 0, 0, dOut, im, iv, 1.0); }, nm, fl);
         }
     }
     for (int wps = 1; wps <= 4; wps *= 2) {
