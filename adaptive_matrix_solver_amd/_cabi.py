@@ -26,7 +26,8 @@ SYMBOLS = [
 POP_X, POP_U, POP_W, POP_Y = 0, 1, 2, 3
 KIND_EIG, KIND_LINEAR, KIND_SVD = 1, 2, 3
 PERT_NONE, PERT_UNIFORM, PERT_MT19937 = 0, 1, 2
-KC_NAMES = ["zgemm", "lu_panel", "trsm", "laswp", "build_h", "backsolve", "vector"]
+KC_NAMES = ["zgemm", "lu_panel", "trsm", "laswp", "build_h", "backsolve", "vector",
+            "zgemm_k128", "zgemm_k64", "zgemm_k32", "zgemm_k16"]
 
 _lib = None
 

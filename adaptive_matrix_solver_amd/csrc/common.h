@@ -61,4 +61,5 @@ __device__ __forceinline__ double wave_sum(double v) {
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // kernel classes for the profiling counters (maus_profile_read)
-enum { KC_GEMM = 0, KC_PANEL = 1, KC_TRSM = 2, KC_LASWP = 3, KC_BUILD = 4, KC_BACKSOLVE = 5, KC_VEC = 6, KC_COUNT = 7 };
+enum { KC_GEMM = 0, KC_PANEL = 1, KC_TRSM = 2, KC_LASWP = 3, KC_BUILD = 4, KC_BACKSOLVE = 5, KC_VEC = 6,
+       KC_GEMM_K128 = 7, KC_GEMM_K64 = 8, KC_GEMM_K32 = 9, KC_GEMM_K16 = 10, KC_COUNT = 11 };   // 7..10: LU recursion GEMMs by K (<256)

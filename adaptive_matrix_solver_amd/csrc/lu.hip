@@ -19,6 +19,7 @@
 //     registers; pivot rule = LAPACK izamax (max |re|+|im|, first index wins).
 #include "common.h"
 #include <climits>
+#include <cstdlib>
 
 void maus_zgemm_launch(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,
                        const c128* B, long ldb, long sB, c128* C, long ldc, long sC,
@@ -26,7 +27,12 @@ void maus_zgemm_launch(hipStream_t st, int M, int N, int K, const c128* A, long 
 
 namespace {
 
-constexpr int NBP = 32;     // base panel width
+#ifndef MAUS_NBP
+#define MAUS_NBP 16
+#endif
+constexpr int NBP = MAUS_NBP;   // base panel width (16: measured best; 32 moves ~4x more in-kernel traffic per panel)
+constexpr int AUG = 32;         // augmented (rhs) column block, also the padding granule of n
+constexpr int BSB = 32;         // back-substitution block
 constexpr int PW = 4;       // register sub-block width inside the panel
 constexpr int PT = 512;     // panel threads (8 waves, 2 per SIMD -> 256 VGPR budget)
 
@@ -75,7 +81,7 @@ build_h_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long strid
         for (int j = threadIdx.x; j < npad; j += blockDim.x) Hrow[j] = cmake(j == i ? 1.0 : 0.0, 0.0);
     }
     // augmented block: column npad = rhs, the other 31 columns zero
-    for (int j = threadIdx.x; j < NBP; j += blockDim.x) {
+    for (int j = threadIdx.x; j < AUG; j += blockDim.x) {
         c128 v = cmake(0.0, 0.0);
         if (j == 0 && i < n) {
             v = (rhs_mode == 0) ? X[(long)slots[g] * ldx + i] : bvec[i];
@@ -99,7 +105,7 @@ load_h_kernel(const c128* __restrict__ Ain /*[G][n][n]*/, const c128* __restrict
         if (i < n && j < n) { v = Ain[((long)g * n + i) * n + j]; bad |= !cfinite(v); }
         Hrow[j] = v;
     }
-    for (int j = threadIdx.x; j < NBP; j += blockDim.x) {
+    for (int j = threadIdx.x; j < AUG; j += blockDim.x) {
         c128 v = cmake(0.0, 0.0);
         if (j == 0 && i < n) { v = bin[(long)g * n + i]; bad |= !cfinite(v); }
         Hrow[npad + j] = v;
@@ -115,7 +121,7 @@ load_h_kernel(const c128* __restrict__ Ain /*[G][n][n]*/, const c128* __restrict
 template <int RPT>
 __global__ void __launch_bounds__(PT)
 lu_panel_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
-                int* __restrict__ ipiv_g, int npad, int* __restrict__ info_g)
+                int* __restrict__ ipiv_g, int npad, int* __restrict__ info_g, int dbg)
 {
     c128* P = Hg + (long)blockIdx.x * strideH + (long)j0 * ld + j0;
     int* ipiv = ipiv_g + (long)blockIdx.x * npad + j0;
@@ -138,13 +144,14 @@ lu_panel_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int r = tid + k * PT;
-            if (r < m) {
+            if (r < m && !(dbg & 8)) {
 #pragma unroll
                 for (int c = 0; c < PW; ++c) R[k][c] = P[(long)r * ld + c0 + c];
             }
         }
 #pragma unroll
         for (int c = 0; c < PW; ++c) {
+            if (dbg & 1) break;
             const int a = c0 + c;            // pivot position (panel-local row == column index)
             // ---- pivot search: max |re|+|im| over rows >= a, first index wins ----
             double best = -1.0; int bidx = INT_MAX;
@@ -185,7 +192,7 @@ lu_panel_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
                 }
             }
             // the other 28 panel columns are swapped in memory
-            if (p != a && tid < NBP && (tid < c0 || tid >= c0 + PW)) {
+            if (p != a && tid < NBP && (tid < c0 || tid >= c0 + PW) && !(dbg & 32)) {
                 c128 x = P[(long)a * ld + tid], y = P[(long)p * ld + tid];
                 P[(long)a * ld + tid] = y; P[(long)p * ld + tid] = x;
             }
@@ -227,7 +234,7 @@ lu_panel_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int r = tid + k * PT;
-            if (r < m) {
+            if (r < m && !(dbg & 16)) {
 #pragma unroll
                 for (int c = 0; c < PW; ++c) P[(long)r * ld + c0 + c] = R[k][c];
                 if (r >= c0 && r < c0 + PW) {
@@ -240,7 +247,7 @@ lu_panel_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
         const int nt = NBP - c0 - PW;     // trailing panel columns
         if (nt > 0) {
             // (d) U12 = L11^-1 * A12 for the 4 pivot rows (unit lower), one lane per column
-            if (tid < nt) {
+            if (tid < nt && !(dbg & 4)) {
                 const int cc = c0 + PW + tid;
                 c128 u[PW];
 #pragma unroll
@@ -258,36 +265,53 @@ lu_panel_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
             //     (x4 for the complex product).  Tiles are loaded/stored a[row=l&15][k=l>>4],
             //     c[r] = C[row=(l>>4)+4r][col=l&15]: 256 contiguous bytes per row and instruction,
             //     instead of the one-row-per-lane pattern of the register sub-block.
-            {
+            if (!(dbg & 2)) {
                 const int rmin = c0 + PW;
                 const int ntile = (m + 15) >> 4;
-                for (int t = (rmin >> 4) + wave; t < ntile; t += PT / 64) {
-                    const int arow = 16 * t + (lane & 15);
-                    c128 av = cmake(0.0, 0.0);
-                    if (arow < m) av = P[(long)arow * ld + c0 + (lane >> 4)];
-                    for (int j = rmin >> 4; j < NBP / 16; ++j) {
-                        const int col = 16 * j + (lane & 15);
-                        const int cc = col - rmin;
-                        c128 bv = cmake(0.0, 0.0);
-                        if (cc >= 0) bv = s_U[lane >> 4][cc];
-                        d4 cre, cim;
+                const int j0t = rmin >> 4;                       // first column tile that still has work (0 or 1)
+                constexpr int NCT = (NBP + 15) / 16;            // 16-column tiles across the panel
+                c128 bv[NCT];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * t + (lane >> 4) + 4 * r;
-                            c128 cv = cmake(0.0, 0.0);
-                            if (row < m) cv = P[(long)row * ld + col];
-                            cre[r] = cv.x; cim[r] = cv.y;
-                        }
-                        cre = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, cre, 0, 0, 1);   // -= Lre*Ure
-                        cim = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.y, cim, 0, 0, 1);   // -= Lre*Uim
-                        cre = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, cre, 0, 0, 0);   // += Lim*Uim
-                        cim = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.x, cim, 0, 0, 1);   // -= Lim*Ure
+                for (int j = 0; j < NCT; ++j) {
+                    const int cc = 16 * j + (lane & 15) - rmin;
+                    bv[j] = (cc >= 0 && cc < NBP - rmin) ? s_U[lane >> 4][cc] : cmake(0.0, 0.0);
+                }
+                // two row tiles per iteration and both column tiles: up to 18 independent 1-KB loads in
+                // flight per wave (this phase is bound by memory-level parallelism per CU)
+                for (int t = (rmin >> 4) + 2 * wave; t < ntile; t += 2 * (PT / 64)) {
+                    c128 av[2], cv[2][NCT][4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * t + (lane >> 4) + 4 * r;
-                            if (row < m && row >= rmin && cc >= 0) P[(long)row * ld + col] = cmake(cre[r], cim[r]);
-                        }
+                    for (int u = 0; u < 2; ++u) {
+                        const int arow = min(16 * (t + u) + (lane & 15), m - 1);
+                        av[u] = P[(long)arow * ld + c0 + (lane >> 4)];
+#pragma unroll
+                        for (int j = 0; j < NCT; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = min(16 * (t + u) + (lane >> 4) + 4 * r, m - 1);
+                                const int col = min(16 * j + (lane & 15), NBP - 1);
+                                cv[u][j][r] = (j >= j0t) ? P[(long)row * ld + col] : cmake(0.0, 0.0);
+                            }
                     }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int j = 0; j < NCT; ++j) {
+                            if (j < j0t) continue;
+                            d4 cre, cim;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { cre[r] = cv[u][j][r].x; cim[r] = cv[u][j][r].y; }
+                            cre = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].x, bv[j].x, cre, 0, 0, 1);   // -= Lre*Ure
+                            cim = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].x, bv[j].y, cim, 0, 0, 1);   // -= Lre*Uim
+                            cre = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].y, bv[j].y, cre, 0, 0, 0);   // += Lim*Uim
+                            cim = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].y, bv[j].x, cim, 0, 0, 1);   // -= Lim*Ure
+                            const int col = 16 * j + (lane & 15);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = 16 * (t + u) + (lane >> 4) + 4 * r;
+                                if (row < m && row >= rmin && col >= rmin && col < NBP) P[(long)row * ld + col] = cmake(cre[r], cim[r]);
+                            }
+                        }
                 }
             }
             __syncthreads();
@@ -348,23 +372,23 @@ trsm32_kernel(c128* __restrict__ Hg, long ld, long strideH, int j, int c_lo, int
 // 32-row blocks from the bottom: dot products of the U row tails against x (LDS), then a
 // 32x32 triangle solved by one wave.  Writes x[0..n) to W[slot]; flags bit1 <- non-finite x.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 backsolve_kernel(const c128* __restrict__ Hg, long ld, long strideH, int n, int npad,
                  c128* __restrict__ Wg, long ldw, const int* __restrict__ slots, c128* __restrict__ xout_dense,
                  int* __restrict__ flags)
 {
     extern __shared__ c128 sx[];          // npad entries of x, then a 32x33 diagonal block, then 32 rhs
     c128* sD = sx + npad;
-    c128* sR = sD + NBP * (NBP + 1);
+    c128* sR = sD + BSB * (BSB + 1);
     const int g = blockIdx.x;
     const c128* H = Hg + (long)g * strideH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     bool bad = false;
-    for (int i0 = npad - NBP; i0 >= 0; i0 -= NBP) {
-        const int jt = i0 + NBP;          // tail starts here
-        // rhs_i = y_i - U[i, jt:] . x[jt:]  ; 4 waves x 8 rows
-        for (int rr = 0; rr < NBP / 4; ++rr) {
-            const int i = i0 + wave * (NBP / 4) + rr;
+    for (int i0 = npad - BSB; i0 >= 0; i0 -= BSB) {
+        const int jt = i0 + BSB;          // tail starts here
+        // rhs_i = y_i - U[i, jt:] . x[jt:]  ; 16 waves x 2 rows
+        for (int rr = 0; rr < BSB / 16; ++rr) {
+            const int i = i0 + wave * (BSB / 16) + rr;
             const c128* row = H + (long)i * ld;
             double sr = 0.0, si = 0.0;
             for (int j = jt + lane; j < npad; j += 64) {
@@ -375,18 +399,18 @@ backsolve_kernel(const c128* __restrict__ Hg, long ld, long strideH, int n, int 
             sr = wave_sum(sr); si = wave_sum(si);
             if (lane == 0) { const c128 y = row[npad]; sR[i - i0] = cmake(y.x - sr, y.y - si); }
         }
-        for (int e = tid; e < NBP * NBP; e += blockDim.x) {
-            int r = e / NBP, c = e % NBP;
-            sD[r * (NBP + 1) + c] = H[(long)(i0 + r) * ld + i0 + c];
+        for (int e = tid; e < BSB * BSB; e += blockDim.x) {
+            int r = e / BSB, c = e % BSB;
+            sD[r * (BSB + 1) + c] = H[(long)(i0 + r) * ld + i0 + c];
         }
         __syncthreads();
         if (wave == 0) {
-            c128 rv = (lane < NBP) ? sR[lane] : cmake(0.0, 0.0);
-            for (int j = NBP - 1; j >= 0; --j) {
-                c128 xj = cdiv(rv, sD[j * (NBP + 1) + j]);        // meaningful on lane j only
+            c128 rv = (lane < BSB) ? sR[lane] : cmake(0.0, 0.0);
+            for (int j = BSB - 1; j >= 0; --j) {
+                c128 xj = cdiv(rv, sD[j * (BSB + 1) + j]);        // meaningful on lane j only
                 xj.x = __shfl(xj.x, j, 64); xj.y = __shfl(xj.y, j, 64);
                 if (lane == j) sx[i0 + j] = xj;
-                if (lane < j) cfms(rv, sD[lane * (NBP + 1) + j], xj);
+                if (lane < j) cfms(rv, sD[lane * (BSB + 1) + j], xj);
             }
         }
         __syncthreads();
@@ -414,11 +438,12 @@ static void lu_gemm(const LuWs& w, int r0, int r1, int c0, int c1, int k0, int k
     // H[r0:r1, c0:c1] -= H[r0:r1, k0:k1] * H[k0:k1, c0:c1]
     int M = r1 - r0, N = c1 - c0, K = k1 - k0;
     if (M <= 0 || N <= 0 || K <= 0) return;
-    prof(w, KC_GEMM, 0);
+    const int kc = (K >= 256) ? KC_GEMM : (K >= 128) ? KC_GEMM_K128 : (K >= 64) ? KC_GEMM_K64 : (K >= 32) ? KC_GEMM_K32 : KC_GEMM_K16;
+    prof(w, kc, 0);
     maus_zgemm_launch(w.st, M, N, K, w.H + (long)r0 * w.ldh + k0, w.ldh, w.strideH,
                       w.H + (long)k0 * w.ldh + c0, w.ldh, w.strideH,
                       w.H + (long)r0 * w.ldh + c0, w.ldh, w.strideH, -1.0, 1, w.G, 0, false, false);
-    prof(w, KC_GEMM, 1, 8.0 * M * N * K * w.G, 16.0 * ((double)M * K + (double)K * N + 2.0 * M * N) * w.G);
+    prof(w, kc, 1, 8.0 * M * N * K * w.G, 16.0 * ((double)M * K + (double)K * N + 2.0 * M * N) * w.G);
 }
 
 static void lu_laswp(const LuWs& w, int k1, int k2, int c_lo, int c_hi) {
@@ -438,7 +463,7 @@ static void lu_trsm(const LuWs& w, int j, int k, int c_lo, int c_hi) {
         prof(w, KC_TRSM, 1, 4.0 * NBP * NBP * (c_hi - c_lo) * w.G, 32.0 * NBP * (c_hi - c_lo) * w.G);
         return;
     }
-    int h = (k >= 64) ? (k / 64) * 32 : 32;
+    int h = (k >= 2 * NBP) ? (k / (2 * NBP)) * NBP : NBP;
     lu_trsm(w, j, h, c_lo, c_hi);
     lu_gemm(w, j + h, j + k, c_lo, c_hi, j, j + h);
     lu_trsm(w, j + h, k - h, c_lo, c_hi);
@@ -449,7 +474,8 @@ static void lu_panel(const LuWs& w, int j0) {
     prof(w, KC_PANEL, 0);
     dim3 grid(w.G), block(PT);
     int rpt = (m + PT - 1) / PT;
-#define PANEL(R) hipLaunchKernelGGL((lu_panel_kernel<R>), grid, block, 0, w.st, w.H, w.ldh, w.strideH, j0, m, w.ipiv, w.npad, w.info)
+    static const int dbg = [] { const char* e = getenv("MAUS_PANEL_DBG"); return e ? atoi(e) : 0; }();   // timing experiments only
+#define PANEL(R) hipLaunchKernelGGL((lu_panel_kernel<R>), grid, block, 0, w.st, w.H, w.ldh, w.strideH, j0, m, w.ipiv, w.npad, w.info, dbg)
     if (rpt <= 1) PANEL(1); else if (rpt <= 2) PANEL(2); else if (rpt <= 4) PANEL(4); else PANEL(8);
 #undef PANEL
     prof(w, KC_PANEL, 1, 8.0 * m * NBP * NBP / 2 * w.G, 16.0 * m * NBP * 8 * w.G);
@@ -457,7 +483,7 @@ static void lu_panel(const LuWs& w, int j0) {
 
 static void lu_recurse(const LuWs& w, int j0, int wd) {
     if (wd <= NBP) { lu_panel(w, j0); return; }
-    int h = (wd / 64) * 32;
+    int h = (wd / (2 * NBP)) * NBP;
     lu_recurse(w, j0, h);
     lu_laswp(w, j0, j0 + h, j0 + h, j0 + wd);
     lu_trsm(w, j0, h, j0 + h, j0 + wd);
@@ -483,13 +509,13 @@ void maus_lu_factor(const LuWs& w, int nbo) {
 
 void maus_lu_backsolve(const LuWs& w, c128* Wpop, long ldw, const int* d_slots, c128* xout_dense) {
     prof(w, KC_BACKSOLVE, 0);
-    size_t shm = sizeof(c128) * ((size_t)w.npad + NBP * (NBP + 1) + NBP);
+    size_t shm = sizeof(c128) * ((size_t)w.npad + BSB * (BSB + 1) + BSB);
     static bool attr_set = false;
     if (!attr_set) {   // up to ~83 KB of dynamic LDS at npad = 4096 (160 KB per CU on gfx950)
         (void)hipFuncSetAttribute((const void*)backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(backsolve_kernel, dim3(w.G), dim3(256), shm, w.st, w.H, w.ldh, w.strideH, w.n, w.npad,
+    hipLaunchKernelGGL(backsolve_kernel, dim3(w.G), dim3(1024), shm, w.st, w.H, w.ldh, w.strideH, w.n, w.npad,
                        Wpop, ldw, d_slots, xout_dense, w.flags);
     prof(w, KC_BACKSOLVE, 1, 4.0 * w.npad * w.npad * w.G, 8.0 * w.npad * w.npad * w.G);
 }

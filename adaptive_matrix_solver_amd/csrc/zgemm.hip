@@ -27,7 +27,7 @@
 
 namespace {
 
-template <int BM, int BN, int BK, int WM, int WN, int BLAY, bool CONJA, bool CONJB, bool M3, bool PIPE, int MINW>
+template <int BM, int BN, int BK, int WM, int WN, int BLAY, bool CONJA, bool CONJB, bool PIPE, int MINW>
 __global__ void __launch_bounds__(64 * WM * WN, MINW)
 zgemm_kernel(int M, int N, int K,
              const c128* __restrict__ Ag, long lda, long strideA,
@@ -63,16 +63,11 @@ zgemm_kernel(int M, int N, int K,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
 
-    // 4M: cre = Re, cim = Im.  3M (Karatsuba): cre = sum Are*Bre, cim = sum Aim*Bim, c3 = sum (Are+Aim)(Bre+Bim);
-    // Re = cre - cim, Im = c3 - cre - cim  (3 MFMAs per block and k-step instead of 4)
-    d4 cre[MB][NB], cim[MB][NB], c3[M3 ? MB : 1][M3 ? NB : 1];
+    d4 cre[MB][NB], cim[MB][NB];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            cre[i][j] = (d4){0, 0, 0, 0}; cim[i][j] = (d4){0, 0, 0, 0};
-            if (M3) c3[i][j] = (d4){0, 0, 0, 0};
-        }
+        for (int j = 0; j < NB; ++j) { cre[i][j] = (d4){0, 0, 0, 0}; cim[i][j] = (d4){0, 0, 0, 0}; }
 
     c128 ra[A_PER], rb[B_PER];
 
@@ -153,21 +148,7 @@ zgemm_kernel(int M, int N, int K,
         for (int j = 0; j < NB; ++j) fb[slot][j] = Bs[krow * LDB_S + wn * WTN + j * 16 + (lane & 15)];
     };
     auto mfma_group = [&](int slot) {
-        if (M3) {
-            double sa[MB], sb[NB];
-#pragma unroll
-            for (int i = 0; i < MB; ++i) sa[i] = fa[slot][i].x + fa[slot][i].y;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) sb[j] = fb[slot][j].x + fb[slot][j].y;
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    cre[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][i].x, fb[slot][j].x, cre[i][j], 0, 0, 0);
-                    cim[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][i].y, fb[slot][j].y, cim[i][j], 0, 0, 0);
-                    c3[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[i], sb[j], c3[i][j], 0, 0, 0);
-                }
-        } else {
+        {
             // first products of every block (independent accumulators back to back) ...
 #pragma unroll
             for (int i = 0; i < MB; ++i)
@@ -245,8 +226,7 @@ zgemm_kernel(int M, int N, int K,
             for (int r = 0; r < 4; ++r) {
                 const int gm = m0 + wm * WTM + i * 16 + (lane >> 4) + 4 * r;
                 if (gm < M && gn < N) {
-                    double vr = cre[i][j][r], vi = cim[i][j][r];
-                    if (M3) { const double p1 = vr, p2 = vi; vr = p1 - p2; vi = (c3[i][j][r] - p1) - p2; }
+                    const double vr = cre[i][j][r], vi = cim[i][j][r];
                     C[off[r]] = cmake(alpha * vr + cold[r].x, alpha * vi + cold[r].y);
                 }
             }
@@ -256,15 +236,13 @@ zgemm_kernel(int M, int N, int K,
 template <int BM, int BN, int BK, int WM, int WN, bool PIPE, int MINW>
 void launch_cfg(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA, const c128* B, long ldb, long sB,
                 c128* C, long ldc, long sC, double alpha, int beta, int batch, int blay, bool conja, bool conjb,
-                const int* a_rows, const int* c_rows, bool m3)
+                const int* a_rows, const int* c_rows)
 {
     int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     int nwg = tiles_m * tiles_n;
     dim3 grid(nwg, batch), block(64 * WM * WN);
-#define LAUNCH(BL, CA, CB) do { if (m3) hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WM, WN, BL, CA, CB, true, PIPE, MINW>), grid, block, 0, st, \
-        M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows); \
-      else hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WM, WN, BL, CA, CB, false, PIPE, MINW>), grid, block, 0, st, \
-        M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows); } while (0)
+#define LAUNCH(BL, CA, CB) hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WM, WN, BL, CA, CB, PIPE, MINW>), grid, block, 0, st, \
+        M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows)
     if (blay == 0) {
         if (!conja && !conjb) LAUNCH(0, false, false);
         else if (!conja && conjb) LAUNCH(0, false, true);
@@ -290,13 +268,8 @@ void maus_zgemm_launch_idx(hipStream_t st, int M, int N, int K, const c128* A, l
                            const int* a_rows, const int* c_rows)
 {
     if (M <= 0 || N <= 0 || batch <= 0) return;
-    // MAUS_GEMM_3M=1: Karatsuba complex product (3 real MFMA products instead of 4; normwise-stable,
-    // Higham 1992).  Off by default: the 4M form has the rounding structure of a scalar FMA chain.
-    static const bool m3 = [] { const char* e = getenv("MAUS_GEMM_3M"); return e && atoi(e) != 0; }();
-    // 128x64 tiles (8 waves, 2/SIMD at one block per CU) once the problem fills the chip with
-    // them; 64x64 (4 waves, two blocks per CU) otherwise.
     static const int cfg = [] { const char* e = getenv("MAUS_GEMM_CFG"); return e ? atoi(e) : 0; }();
-#define ARGS st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, batch, blay, conja, conjb, a_rows, c_rows, m3
+#define ARGS st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, batch, blay, conja, conjb, a_rows, c_rows
     // Default: 64x64 tiles, 4 waves per workgroup, <= 128 VGPRs and 33 KB of LDS so that FOUR independent
     // workgroups share a CU (4 waves per SIMD).  Measured on MI355X (tools/gemm_sweep*.py, K=256, 136
     // matrices): 66 TFLOP/s, against 50-55 for every one-workgroup-per-CU variant (128x64 / 128x128

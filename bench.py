@@ -130,9 +130,15 @@ def main():
     ctx.profile_enable(False)
 
     if rank == 0:
-        g = prof["zgemm"]
+        # every LU / matvec GEMM is the same kernel (zgemm_kernel<64,64,16,...>); the profile classes
+        # only split its launches by K so the small-K recursion levels can be told apart
+        gk = [k for k in prof if k.startswith("zgemm")]
+        g = {"ms": sum(prof[k]["ms"] for k in gk), "flops": sum(prof[k]["flops"] for k in gk),
+             "launches": sum(prof[k]["launches"] for k in gk)}
+        big = prof["zgemm"]
         tot_ms = sum(v["ms"] for v in prof.values())
         achieved = (g["flops"] / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else 0.0
+        achieved_big = (big["flops"] / (big["ms"] * 1e-3) / 1e12) if big["ms"] > 0 else 0.0
         per_launch_ms = g["ms"] / max(1, g["launches"])
         out = {
             "metric": "candidate-steps/sec, n=4096 dense eig pop=256, 1/2/4/8 GPUs vs CPU ref",
@@ -147,13 +153,14 @@ def main():
                        "parallelism": "A replicated, active candidates block-sharded over ranks, all-gather of records per phase",
                        "pert_mode": "none(inert 0.15*psi term dropped; NumPy stream advanced by MT19937 jump)" if n > 256 else "uniform",
                        "device": info["name"], "solver_build_s": round(t_build, 2)},
-            "roofline": {"bound": "mfma", "kernel": "zgemm_kernel (LU trailing update, v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "kernel": "zgemm_kernel<64,64,16> (LU trailing updates, v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "launches": g["launches"], "avg_launch_ms": per_launch_ms,
                          "flops_per_launch": g["flops"] / max(1, g["launches"]),
                          "kernel_time_share": (g["ms"] / tot_ms) if tot_ms > 0 else None,
-                         "measured_mfma_f64_issue_ceiling_tflops": 48.6},
+                         "achieved_k256_launches_only": achieved_big,
+                         "measured_mfma_f64_issue_rate_tflops": 77.9},
             "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
             "step_tflops": (8.0 / 3.0 * n ** 3 + 24.0 * n * n) * steps_done / elapsed / 1e12,
         }

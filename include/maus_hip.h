@@ -146,7 +146,8 @@ int maus_lu_solve_host(maus_ctx* ctx, int count, int n, const double* a_c128, co
 int maus_timer_start(maus_ctx* ctx);
 int maus_timer_stop(maus_ctx* ctx, float* ms_out);
 /* Per-kernel-class accounting (event pairs around each launch of the class while enabled).
- * classes: 0 zgemm (LU trailing update / A@X), 1 lu_panel, 2 trsm, 3 laswp, 4 build_H, 5 backsolve, 6 vector ops */
+ * classes: 0 zgemm (LU trailing update with K>=256 / A@X), 1 lu_panel, 2 trsm, 3 laswp, 4 build_H, 5 backsolve,
+ * 6 vector ops, 7..10 zgemm inside the LU recursion with K = 128 / 64 / 32 / 16 */
 int maus_profile_enable(maus_ctx* ctx, int on);
 int maus_profile_read(maus_ctx* ctx, int klass, int* launches, double* total_ms, double* flops, double* bytes);
 int maus_sync(maus_ctx* ctx);
