@@ -53,7 +53,17 @@ zgemm_kernel(int M, int N, int K,
         int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    // L2 blocking: tiles are walked column-block-major (WC tile columns wide, all tile rows), so the
+    // B block of the current column block (WC x BN x K) stays resident in the XCD's 4 MB L2 while the
+    // A row panels stream past it once.  Row-major order re-streamed all of B for every tile row
+    // (PMC: FETCH_SIZE 3.5x the algorithmic reads; profiles/r01_pmc_traffic_before_l2_blocking.txt).
+    constexpr int WC = 8;
+    const int tiles_m = nwg / tiles_n;
+    const int full = tiles_m * WC;
+    int cb = bid / full, rem = bid - cb * full, wl = WC;
+    const int ncb = (tiles_n + WC - 1) / WC;
+    if (cb >= ncb - 1) { cb = ncb - 1; rem = bid - cb * full; wl = tiles_n - cb * WC; }
+    const int tm = rem / wl, tn = cb * WC + (rem - tm * wl);
     const int m0 = tm * BM, n0 = tn * BN;
     const long batch = blockIdx.y;
     const c128* A = Ag + batch * strideA;
