@@ -267,6 +267,18 @@ void launch_cfg(hipStream_t st, int M, int N, int K, const c128* A, long lda, lo
 #undef LAUNCH
 }
 
+// plain-layout-only instantiation (LU trailing updates): one kernel per tile shape instead of eight
+template <int BM, int BN, int BK, int WM, int WN>
+void launch_lu_only(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA, const c128* B, long ldb, long sB,
+                    c128* C, long ldc, long sC, double alpha, int beta, int batch, int, bool, bool,
+                    const int* a_rows, const int* c_rows)
+{
+    int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    int nwg = tiles_m * tiles_n;
+    hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WM, WN, 0, false, false, false, 4>), dim3(nwg, batch), dim3(64 * WM * WN), 0, st,
+                       M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows);
+}
+
 }  // namespace
 
 // Host-side launcher (device pointers).  batch matrices at element strides sA/sB/sC.
@@ -285,8 +297,16 @@ void maus_zgemm_launch_idx(hipStream_t st, int M, int N, int K, const c128* A, l
     // matrices): 66 TFLOP/s, against 50-55 for every one-workgroup-per-CU variant (128x64 / 128x128
     // tiles, BK 16/32, with or without the software-pipelined loop): with both waves of a SIMD in
     // the same workgroup they run in lockstep and every wait or barrier of one is a bubble for both.
-    if (cfg == 1 && M >= 128) launch_cfg<128, 64, 16, 4, 2, true, 2>(ARGS);     // reference: pipelined, 1 WG/CU
-    else launch_cfg<64, 64, 16, 2, 2, false, 4>(ARGS);
+    if (cfg == 1 && M >= 128) { launch_cfg<128, 64, 16, 4, 2, true, 2>(ARGS); return; }   // reference: pipelined, 1 WG/CU
+    // skinny shapes of the LU recursion (plain layout only): keep the 32x32 / 16x32 wave tile but shape
+    // the workgroup tile like the problem so no MFMA runs on padding
+    if (blay == 0 && !conja && !conjb && cfg != 2) {
+        if (N <= 16) { launch_lu_only<128, 16, 16, 4, 1>(ARGS); return; }
+        if (N <= 32) { launch_lu_only<128, 32, 16, 4, 1>(ARGS); return; }
+        if (M <= 16) { launch_lu_only<16, 128, 16, 1, 4>(ARGS); return; }
+        if (M <= 32) { launch_lu_only<32, 128, 16, 1, 4>(ARGS); return; }
+    }
+    launch_cfg<64, 64, 16, 2, 2, false, 4>(ARGS);
 #undef ARGS
 }
 

@@ -140,6 +140,16 @@ def main():
         achieved = (g["flops"] / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else 0.0
         achieved_big = (big["flops"] / (big["ms"] * 1e-3) / 1e12) if big["ms"] > 0 else 0.0
         per_launch_ms = g["ms"] / max(1, g["launches"])
+        g["bytes"] = sum(prof[k]["bytes"] for k in gk)
+        # HBM bytes per zgemm launch from the committed PMC passes of this same command (rocprofv3 cannot
+        # be combined with the timed run; see profiles/r01_zgemm_pmc_traffic.json for the recipe)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_zgemm_pmc_traffic.json")) as f:
+                if n == 4096 and P == 256 and world == 1:
+                    traffic = json.load(f)["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "candidate-steps/sec, n=4096 dense eig pop=256, 1/2/4/8 GPUs vs CPU ref",
             "value": steps_done / elapsed, "unit": "candidate-steps/s",
@@ -155,7 +165,8 @@ def main():
                        "device": info["name"], "solver_build_s": round(t_build, 2)},
             "roofline": {"bound": "mfma", "kernel": "zgemm_kernel<64,64,16> (LU trailing updates, v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["launches"]),
                          "launches": g["launches"], "avg_launch_ms": per_launch_ms,
                          "flops_per_launch": g["flops"] / max(1, g["launches"]),
                          "kernel_time_share": (g["ms"] / tot_ms) if tot_ms > 0 else None,
