@@ -149,7 +149,7 @@ class Context:
         return float(ms.value)
 
     def profile_enable(self, on=True):
-        self._ck(self.lib.maus_profile_enable(self.h, 1 if on else 0), "maus_profile_enable")
+        self._ck(self.lib.maus_profile_enable(self.h, int(on)), "maus_profile_enable")
 
     def profile_read(self):
         out = {}

@@ -53,6 +53,12 @@ int upload_slots(maus_ctx* c, const int* slots, int count) {
 void prof_tick(void* ud, int klass, int phase, double flops, double bytes) {
     maus_ctx* c = (maus_ctx*)ud;
     if (!c->prof_on) return;
+    if (phase == 0) {
+        c->total_launches[klass]++;
+        const bool is_gemm = (klass == KC_GEMM || klass >= KC_GEMM_K128);
+        c->prof_skip = (c->prof_mode == 2) && (!is_gemm || (c->prof_seq++ % 5) != 0);
+    }
+    if (c->prof_skip) return;
     auto get = [&]() { hipEvent_t e; if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
     hipStream_t st = c->prof_st ? c->prof_st : c->st;
     if (phase == 0) { c->cur0 = get(); (void)hipEventRecord(c->cur0, st); }
@@ -538,7 +544,9 @@ int maus_timer_stop(maus_ctx* c, float* ms) {
 int maus_profile_enable(maus_ctx* c, int on) {
     prof_resolve(c);
     c->prof_on = on != 0;
-    if (on) for (int k = 0; k < KC_COUNT; ++k) { c->launches[k] = 0; c->ms[k] = 0; c->flops[k] = 0; c->bytes[k] = 0; }
+    c->prof_mode = (on == 2) ? 2 : 1;
+    c->prof_seq = 0;
+    if (on) for (int k = 0; k < KC_COUNT; ++k) { c->launches[k] = 0; c->ms[k] = 0; c->flops[k] = 0; c->bytes[k] = 0; c->total_launches[k] = 0; }
     return 0;
 }
 

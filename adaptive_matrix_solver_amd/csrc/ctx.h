@@ -66,6 +66,9 @@ struct maus_ctx {
     // measurement
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool prof_on = false;
+    int prof_mode = 1;            // 1: every launch of every class; 2: every 5th launch of the zgemm classes only
+    long prof_seq = 0; bool prof_skip = false;
+    int total_launches[KC_COUNT] = {0};
     std::vector<ProfRec> pending;
     std::vector<hipEvent_t> pool;
     hipEvent_t cur0 = nullptr;
