@@ -52,6 +52,33 @@ def _advance_numpy_stream(nwords: int) -> None:
     np.random.set_state((st[0], key, pos, st[3], st[4]))
 
 
+class _AsyncStreamAdvance:
+    """Compute the NumPy-stream advance of a whole run on a worker thread while the GPU executes the
+    batch (the jump polynomial x^J mod phi costs ~20 ms for a new J; ctypes releases the GIL).  The
+    result is applied only if the run completes without RNG events; otherwise it is discarded and
+    the exact sequential replay takes over."""
+
+    def __init__(self, nwords: int):
+        import threading
+        self.nwords = nwords
+        self.state = np.random.get_state()
+        self.result = None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        self.result = _cabi.mt19937_jump(self.state[1], self.state[2], self.nwords)
+
+    def apply(self):
+        self.thread.join()
+        key, pos = self.result
+        st = self.state
+        np.random.set_state((st[0], key, pos, st[3], st[4]))
+
+    def discard(self):
+        self.thread.join()
+
+
 class DeviceEngine:
     """One GPU context + slot allocator + the batched step."""
 
@@ -467,6 +494,10 @@ class DeviceEngine:
                     pert_data[k, 0] = np.random.rand(n, n)
                     pert_data[k, 1] = np.random.rand(n, n)
                     rng_after.append(np.random.get_state())
+            per_cand_words = words * (2 if legacy_gmres else 1)
+            ahead = None
+            if pert != PERT_UNIFORM and len(run) >= 8:
+                ahead = _AsyncStreamAdvance(per_cand_words * len(run))       # overlaps the GPU batch below
             if first_method == DIRECT or legacy_gmres:
                 status = self.d_lu_solve(run, shift, psi0, 0 if is_eig else 1, pert, pert_data)
                 ok = status == 0
@@ -485,14 +516,16 @@ class DeviceEngine:
                     if tiny.size:
                         e4 = int(tiny[0])
             nvalid = nb if (e4 is None or pert != PERT_UNIFORM) else e4 + 1
-            per_cand_words = words * (2 if legacy_gmres else 1)
+            clean = ahead is not None and nvalid == len(run) and e4 is None
+            if ahead is not None and not clean:
+                ahead.discard()
             # --- RNG replay + bookkeeping for the accepted candidates, in list order ---
             if pert == PERT_UNIFORM:
                 np.random.set_state(rng_after[nvalid - 1] if nvalid > 0 else rng_start)
             pending_words = 0          # E3 consumption not yet applied to the stream (one jump per run)
             for k in range(nvalid):
                 c = run[k]
-                if pert != PERT_UNIFORM:
+                if pert != PERT_UNIFORM and not clean:
                     pending_words += per_cand_words                     # E3
                 c.local_psi_retries_needed = 0                          # attempts == 0 (AMS:278)
                 c._invalidate()
@@ -502,7 +535,10 @@ class DeviceEngine:
                     c.v_k = (np.random.rand(n) + 1j * np.random.rand(n)) / np.sqrt(n)     # E4 (AMS:283)
                     c._push(force=True)
                 c.stuck_counter = max(0, c.stuck_counter - 1)           # AMS:286
-            _advance_numpy_stream(pending_words)
+            if clean:
+                ahead.apply()                                           # whole run's E3 consumption, precomputed
+            else:
+                _advance_numpy_stream(pending_words)
             if pert == PERT_UNIFORM and nvalid < nb:
                 for c in run[nvalid:nb]:                                # speculative relax undone
                     c._restore_device()
