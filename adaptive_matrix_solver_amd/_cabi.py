@@ -29,6 +29,14 @@ PERT_NONE, PERT_UNIFORM, PERT_MT19937 = 0, 1, 2
 KC_NAMES = ["zgemm", "lu_panel", "trsm", "laswp", "build_h", "backsolve", "vector",
             "zgemm_k128", "zgemm_k64", "zgemm_k32", "zgemm_k16"]
 
+
+
+class MtDesc(C.Structure):
+    """maus_mt_desc (include/maus_hip.h)."""
+    _fields_ = [("key", C.c_uint32 * 624), ("pos", C.c_int32), ("reserved", C.c_int32),
+                ("words_per_candidate", C.c_uint64), ("lead_words", C.c_uint64), ("ordinals", C.POINTER(C.c_int32))]
+
+
 _lib = None
 
 
@@ -216,11 +224,23 @@ class Context:
         assert ps.shape == (k,)
         status = np.zeros(k, dtype=np.int32)
         pd = None
+        pdp = None
         if pert_mode == PERT_UNIFORM:
             pd = np.ascontiguousarray(pert_data, dtype=np.float64)
             assert pd.shape == (k, 2, self.rows, self.rows), pd.shape
+            pdp = _ptr(pd)
+        elif pert_mode == PERT_MT19937:
+            # pert_data = (numpy_state, words_per_candidate, lead_words, ordinals)
+            st, wpc, lead, ords = pert_data
+            ords = np.ascontiguousarray(ords, dtype=np.int32)
+            assert ords.shape == (k,)
+            pd = MtDesc()
+            C.memmove(pd.key, np.ascontiguousarray(st[1], dtype=np.uint32).ctypes.data, 624 * 4)
+            pd.pos = int(st[2]); pd.words_per_candidate = int(wpc); pd.lead_words = int(lead)
+            pd.ordinals = ords.ctypes.data_as(C.POINTER(C.c_int32))
+            pdp = C.cast(C.pointer(pd), C.c_void_p)
         self._ck(self.lib.maus_shifted_lu_solve(self.h, _ptr(s), k, _ptr(sh), _ptr(ps), int(rhs_mode), int(pert_mode),
-                                                _ptr(pd), _ptr(status)), "maus_shifted_lu_solve")
+                                                pdp, _ptr(status)), "maus_shifted_lu_solve")
         return status
 
     def relax_normalise(self, slots, alpha, normalise=True):

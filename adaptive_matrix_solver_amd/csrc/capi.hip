@@ -100,8 +100,9 @@ int maus_ctx_destroy(maus_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
     void* ptrs[] = {c->A, c->b, c->V, c->X, c->U, c->W, c->Y, c->d_slots, c->d_i1, c->d_i2, c->d_c1, c->d_c2, c->d_r1, c->d_r2,
-                    c->H, c->ipiv, c->info, c->flags, c->Upert, c->scratch};
+                    c->H, c->ipiv, c->info, c->flags, c->Upert, c->scratch, c->mt_states, c->mt_int, c->mt_base};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& kv : c->mt_taps) if (kv.second.first) (void)hipFree(kv.second.first);
     for (auto& r : c->pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     for (auto st : c->lu_st) (void)hipStreamDestroy(st);
@@ -308,13 +309,108 @@ static void finish_status(int G, const int* info, const int* flags, int32_t* sta
     }
 }
 
+
+// MAUS_PERT_MT19937: generator start states for candidates [first, first+g) of the run by binary lifting (over the
+// draw index m, then over the sub-stream index b), then the H build that regenerates the draws (mtdev.hip).
+static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* d, int first, int g, int rhs_mode, int lo) {
+    const int n = w.n;
+    const uint64_t two_n2 = 2ull * n * n;
+    if (d->pos < 0 || d->pos > 624) FAIL(c, "maus_mt_desc: bad position");
+    if (d->words_per_candidate % two_n2 || d->lead_words % two_n2 || d->words_per_candidate < 2 * two_n2 || !d->ordinals)
+        FAIL(c, "maus_mt_desc: words_per_candidate / lead_words must be multiples of 2*n*n");
+    // sub-streams per draw: enough workgroups to cover the chip a few times, each at least ~64 blocks long
+    int S = std::max(1, std::min(8, 768 / std::max(1, g)));
+    const uint64_t nn = (uint64_t)n * n;
+    while (S > 1 && nn / S < 64 * 312) --S;
+    { const char* e = getenv("MAUS_MT_SUBSTREAMS"); if (e) S = std::max(1, std::min(16, atoi(e))); }
+    const uint64_t E = (nn + S - 1) / S;                          // elements per sub-stream
+    const int ngen = 2 * g * S;
+    if (ngen > c->mt_cap) {
+        void** ps[] = {(void**)&c->mt_states, (void**)&c->mt_base};
+        for (auto p : ps) if (*p) { (void)hipFree(*p); *p = nullptr; }
+        const int cap = std::max(ngen, 4096);
+        HIPCHK(c, hipMalloc((void**)&c->mt_states, sizeof(uint32_t) * 624 * (size_t)cap));
+        HIPCHK(c, hipMalloc((void**)&c->mt_base, sizeof(uint32_t) * 624));
+        c->mt_cap = cap;
+    }
+    const uint64_t dblocks = two_n2 / 624;
+    const uint64_t dj = dblocks >= 2 ? dblocks - 1 : 0;          // jump stride (blocks) per draw; >= 1 real regeneration follows
+    const uint64_t sblocks = (2 * E) / 624;
+    const uint64_t dj2 = (S > 1 && sblocks >= 2) ? sblocks - 1 : 0;   // jump stride (blocks) per sub-stream
+    std::vector<uint64_t> m(ngen), bsel(ngen);
+    // staging layout: extra[ngen] | rpos[ngen] | selection lists of every lifting level
+    std::vector<int>& hs = c->mt_host;
+    hs.assign(2 * (size_t)ngen, 0);
+    uint64_t maxm = 0, maxb = 0;
+    for (int k = 0; k < g; ++k) {
+        const uint64_t ord = (uint64_t)d->ordinals[first + k];
+        for (int sb = 0; sb < S; ++sb)
+            for (int part = 0; part < 2; ++part) {
+                const int gi = (k * S + sb) * 2 + part;
+                const uint64_t mm = (d->lead_words + ord * d->words_per_candidate) / two_n2 + part;
+                const uint64_t t = (uint64_t)d->pos + mm * two_n2 + 2ull * sb * E;
+                const uint64_t q = t / 624;
+                m[gi] = dj ? mm : 0;
+                bsel[gi] = dj2 ? (uint64_t)sb : 0;
+                const uint64_t ex = q - m[gi] * dj - bsel[gi] * dj2;
+                if (ex > 2000000000ull) FAIL(c, "maus_mt_desc: stream offset too large");
+                hs[gi] = (int)ex;
+                hs[ngen + gi] = (int)(t % 624);
+                maxm = std::max(maxm, m[gi]); maxb = std::max(maxb, bsel[gi]);
+            }
+    }
+    struct Level { size_t off; int count; const int* taps; int ntap16; };
+    std::vector<Level> levels;
+    auto plan = [&](const std::vector<uint64_t>& idx, uint64_t maxv, uint64_t stride_blocks) -> int {
+        for (int bit = 0; stride_blocks && (maxv >> bit); ++bit) {
+            const size_t off = hs.size();
+            for (int i = 0; i < ngen; ++i) if ((idx[i] >> bit) & 1ull) hs.push_back(i);
+            const int cnt = (int)(hs.size() - off);
+            if (!cnt) continue;
+            const uint64_t J = 624ull * stride_blocks * (1ull << bit);
+            auto it = c->mt_taps.find(J);
+            if (it == c->mt_taps.end()) {                       // tap list of x^J mod phi, cached on the device
+                std::vector<uint64_t> poly(312);
+                if (maus_mt_jump_poly(J, poly.data())) FAIL(c, "MT19937 jump polynomial failed");
+                std::vector<int> taps;
+                for (int i = 0; i < 19937; ++i) if ((poly[i >> 6] >> (i & 63)) & 1ull) taps.push_back(i);
+                while (taps.size() % 16) taps.push_back(maus_mt_zero_tap());
+                int* dt = nullptr;
+                HIPCHK(c, hipMalloc((void**)&dt, sizeof(int) * taps.size()));
+                HIPCHK(c, hipMemcpy(dt, taps.data(), sizeof(int) * taps.size(), hipMemcpyHostToDevice));
+                it = c->mt_taps.emplace(J, std::make_pair(dt, (int)(taps.size() / 16))).first;
+            }
+            levels.push_back({off, cnt, it->second.first, it->second.second});
+        }
+        return 0;
+    };
+    if (plan(m, maxm, dj)) return -1;
+    if (plan(bsel, maxb, dj2)) return -1;
+    if (hs.size() > c->mt_int_cap) {
+        if (c->mt_int) { (void)hipFree(c->mt_int); c->mt_int = nullptr; }
+        const size_t cap = hs.size() * 2;
+        HIPCHK(c, hipMalloc((void**)&c->mt_int, sizeof(int) * cap));
+        c->mt_int_cap = cap;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->mt_base, d->key, sizeof(uint32_t) * 624, hipMemcpyHostToDevice, w.st));
+    HIPCHK(c, hipMemcpyAsync(c->mt_int, hs.data(), sizeof(int) * hs.size(), hipMemcpyHostToDevice, w.st));
+    HIPCHK(c, hipStreamSynchronize(w.st));                       // staging (hs, d->key) is reusable from here on
+    maus_mt_copy_states(w.st, c->mt_states, c->mt_base, ngen);
+    for (const Level& L : levels) maus_mt_jump(w.st, c->mt_states, c->mt_int + L.off, L.count, L.taps, L.ntap16);
+    const int* d_extra = c->mt_int; const int* d_rpos = c->mt_int + ngen;
+    prof_tick(c, KC_BUILD, 0, 0, 0);
+    maus_build_h_mt(w.st, c->A, n, w.npad, w.ldh, w.strideH, w.H, g, S, (long)E, c->d_c1 + lo, c->d_r1 + lo, rhs_mode, c->X, c->ldp,
+                    c->d_slots + lo, c->b, c->mt_states, d_extra, d_rpos, w.flags);
+    prof_tick(c, KC_BUILD, 1, 0, 32.0 * w.npad * w.ldh * g);
+    return 0;
+}
+
 int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double* shift, const double* psi,
                           int rhs_mode, int pert_mode, const void* pert_data, int32_t* status) {
     if (!c->A || !c->X) FAIL(c, "maus_shifted_lu_solve: matrix/population missing");
     if (c->rows != c->cols) FAIL(c, "maus_shifted_lu_solve: square matrix required");
     if (rhs_mode == 1 && (!c->b || c->bn != c->rows)) FAIL(c, "maus_shifted_lu_solve: rhs b not set");
-    if (pert_mode == MAUS_PERT_MT19937) FAIL(c, "MAUS_PERT_MT19937 not available in this build");
-    if (pert_mode == MAUS_PERT_UNIFORM && !pert_data) FAIL(c, "pert_data missing");
+    if ((pert_mode == MAUS_PERT_UNIFORM || pert_mode == MAUS_PERT_MT19937) && !pert_data) FAIL(c, "pert_data missing");
     if (count == 0) return 0;
     const int n = c->rows;
     if (check_slots(c, slots, count)) return -1;
@@ -351,6 +447,9 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             LuWs w = make_ws(c, n, g);
             w.H += (long)lo * w.strideH; w.ipiv += (long)lo * w.npad; w.info += lo; w.flags += lo; w.st = st;
             c->prof_st = st;
+            if (pert_mode == MAUS_PERT_MT19937) {
+                if (mt_prepare_and_build(c, w, (const maus_mt_desc*)pert_data, off + lo, g, rhs_mode, lo)) return -1;
+            } else
             maus_build_h(w, c->A, c->d_c1 + lo, c->d_r1 + lo, rhs_mode, c->X, c->ldp, c->d_slots + lo, c->b, pert_mode,
                          dU ? dU + 2 * (size_t)n * n * lo : nullptr);
             maus_lu_factor(w, lu_nbo());

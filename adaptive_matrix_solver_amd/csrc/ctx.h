@@ -3,6 +3,7 @@
 #include "common.h"
 #include "../../include/maus_hip.h"
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,13 @@ void maus_build_h(const LuWs& w, const c128* A, const c128* d_shift, const doubl
                   const c128* X, long ldx, const int* d_slots, const c128* bvec, int pert_mode, const double* d_U);
 void maus_load_h(const LuWs& w, const c128* d_Ain, const c128* d_bin);
 int maus_lu_max_npad();
+void maus_mt_copy_states(hipStream_t st, uint32_t* states, const uint32_t* base, int count);
+void maus_mt_jump(hipStream_t st, uint32_t* states, const int* sel, int nsel, const int* taps, int ntap16);
+int maus_mt_zero_tap();
+void maus_build_h_mt(hipStream_t st, const c128* A, int n, int npad, long ldh, long strideH, c128* H, int G, int S, long E,
+                     const c128* d_shift, const double* d_psi, int rhs_mode, const c128* X, long ldx, const int* d_slots,
+                     const c128* bvec, const uint32_t* states, const int* extra, const int* rpos, int* flags);
+int maus_mt_jump_poly(uint64_t J, uint64_t* out312);
 void maus_zgemm_launch_idx(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,
                            const c128* B, long ldb, long sB, c128* C, long ldc, long sC,
                            double alpha, int beta, int batch, int blay, bool conja, bool conjb,
@@ -57,6 +65,10 @@ struct maus_ctx {
     c128* H = nullptr; size_t Hbytes = 0; int Hg = 0; int Hnpad = 0;
     int *ipiv = nullptr, *info = nullptr, *flags = nullptr;
     double* Upert = nullptr; size_t Ubytes = 0;
+    // device-side MT19937 regeneration (mtdev.hip)
+    uint32_t* mt_states = nullptr; int* mt_int = nullptr; uint32_t* mt_base = nullptr; int mt_cap = 0; size_t mt_int_cap = 0;
+    std::map<uint64_t, std::pair<int*, int>> mt_taps;   // J -> (device tap list of x^J mod phi, #taps/16)
+    std::vector<int> mt_host;                           // staging for the per-level selections
     // sub-batch streams: bandwidth-bound phases (panel, swaps, trsm) of one sub-batch overlap the
     // MFMA-bound trailing updates of another
     std::vector<hipStream_t> lu_st; std::vector<hipEvent_t> lu_done; hipEvent_t ev_stage = nullptr;

@@ -209,3 +209,18 @@ extern "C" int maus_mt19937_jump(uint32_t* key, int32_t* pos, uint64_t nwords) {
     *pos = newpos;
     return 0;
 }
+
+// x^J mod phi as 312 little-endian 64-bit words (bit i = coefficient of x^i); cached.  Used by the device-side
+// stream regeneration (mtdev.hip) for its binary-lifting jumps.
+int maus_mt_jump_poly(uint64_t J, uint64_t* out312) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_phi_ok) { if (!init_phi()) return -2; g_phi_ok = true; }
+    auto it = g_cache.find(J);
+    if (it == g_cache.end()) {
+        Poly g; poly_pow_x(J, g);
+        if (g_cache.size() > 256) g_cache.clear();
+        it = g_cache.emplace(J, g).first;
+    }
+    memcpy(out312, it->second.w, sizeof(uint64_t) * PW);
+    return 0;
+}

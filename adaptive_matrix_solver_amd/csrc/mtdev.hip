@@ -1,0 +1,239 @@
+// Device-side regeneration of the legacy NumPy MT19937 stream for the dense regulariser (AMS:49-50,
+// SURVEY F4 / §8f row f-1):  reg = psi*I + 0.15*psi*((U1-.5) + i(U2-.5)),  U1 then U2 = np.random.rand(N,N),
+// i.e. 4*N*N consecutive MT19937 words per solve attempt.  With MAUS_PERT_MT19937 the H_k are built
+// from bit-identical draws without the host ever materialising them:
+//
+//  1. every candidate needs two generator start states (U1 and U2), all at offsets m * 2N^2 words from
+//     the current NumPy state.  They are reached by binary lifting over m with jump polynomials
+//     g_i(x) = x^(624*Dj*2^i) mod phi (host, cached; Dj = floor(2N^2/624) - 1 blocks).  A jump is
+//     evaluated as a CONVOLUTION: g(F) s = sum_i g_i F^i s and F^i s is the stream shifted by i words,
+//     so out[j] = XOR_{i : g_i = 1} x[i + j] over the next 19937+624 words -- no 19937-step Horner chain.
+//  2. S workgroups per candidate (each owning a contiguous range of elements, reached by a second lifting
+//     over the sub-stream index) then walk both streams block by block (the 624-word regeneration
+//     has three dependency phases of 227/227/170 words), tempers, converts word pairs to doubles
+//     exactly as NumPy's legacy random_sample does ((a>>5)*2^26 + (b>>6)) / 2^53, and writes
+//     H = (A - lambda*delta) + (psi*delta + ((u-.5)*psi)*0.15) with NumPy's rounding order.
+#include "common.h"
+#include <cstdint>
+
+namespace {
+
+constexpr int MTN = 624, MTM = 397, MTD = 227;          // MTD = MTN - MTM
+constexpr uint32_t UPM = 0x80000000u, LOM = 0x7fffffffu, MAG = 0x9908b0dfu;
+constexpr int PDEG = 19937;
+constexpr int PWORDS = 624;                              // polynomial bit array, 32-bit words (19968 bits)
+constexpr int CONVN = PDEG + MTN;                        // words of stream a jump needs (20561)
+constexpr int CONV_BLOCKS = (CONVN + MTN - 1) / MTN;     // 33 blocks
+
+__device__ __forceinline__ uint32_t twist(uint32_t u, uint32_t v) {
+    const uint32_t y = (u & UPM) | (v & LOM);
+    return (y >> 1) ^ ((y & 1u) ? MAG : 0u);
+}
+
+// next block `nw` from block `od` (both time-ordered in LDS); all threads of the block take part
+__device__ __forceinline__ void regen_block(const uint32_t* od, uint32_t* nw, int tid, int nthreads) {
+    for (int k = tid; k < MTD; k += nthreads) nw[k] = od[k + MTM] ^ twist(od[k], od[k + 1]);
+    __syncthreads();
+    for (int k = MTD + tid; k < 2 * MTD; k += nthreads) nw[k] = nw[k - MTD] ^ twist(od[k], od[k + 1]);
+    __syncthreads();
+    for (int k = 2 * MTD + tid; k < MTN; k += nthreads)
+        nw[k] = nw[k - MTD] ^ twist(od[k], (k == MTN - 1) ? nw[0] : od[k + 1]);
+    __syncthreads();
+}
+
+// states[g] <- g(F) states[g] for the generators listed in `sel`.  g is given as the list of its set
+// coefficients (`taps`, padded to a multiple of 16 with ZTAP, which points at a zero region), so
+// out[j] = XOR_t x[taps[t] + j] over the generator's own next 19937+624 words: a GF(2) convolution.
+// The tap indices are wave-uniform (scalar loads); each iteration issues 16 independent LDS reads.
+constexpr int JT = 640;                                  // one output word per thread (624 used)
+constexpr int XS_WORDS = CONV_BLOCKS * MTN;              // 20592
+constexpr int ZTAP = XS_WORDS;                           // xs[ZTAP .. ZTAP+JT) == 0
+__global__ void __launch_bounds__(JT)
+mt_jump_kernel(uint32_t* __restrict__ states, const int* __restrict__ sel, const int* __restrict__ taps, int ntap16)
+{
+    __shared__ uint32_t xs[XS_WORDS + JT];
+    const int tid = threadIdx.x;
+    uint32_t* S = states + (long)sel[blockIdx.x] * MTN;
+    for (int k = tid; k < MTN; k += JT) xs[k] = S[k];
+    xs[ZTAP + tid] = 0u;
+    __syncthreads();
+    for (int b = 1; b < CONV_BLOCKS; ++b) regen_block(xs + (b - 1) * MTN, xs + b * MTN, tid, JT);
+    const uint32_t* xt = xs + tid;
+    uint32_t acc0 = 0u, acc1 = 0u, acc2 = 0u, acc3 = 0u;
+    for (int t = 0; t < ntap16; ++t) {
+        const int4* tp = reinterpret_cast<const int4*>(taps + 16 * t);
+        const int4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
+        acc0 ^= xt[a.x] ^ xt[a.y] ^ xt[a.z] ^ xt[a.w];
+        acc1 ^= xt[b.x] ^ xt[b.y] ^ xt[b.z] ^ xt[b.w];
+        acc2 ^= xt[c.x] ^ xt[c.y] ^ xt[c.z] ^ xt[c.w];
+        acc3 ^= xt[d.x] ^ xt[d.y] ^ xt[d.z] ^ xt[d.w];
+    }
+    if (tid < MTN) S[tid] = acc0 ^ acc1 ^ acc2 ^ acc3;
+}
+
+__global__ void mt_copy_state_kernel(uint32_t* __restrict__ states, const uint32_t* __restrict__ base, int count) {
+    const int g = blockIdx.x;
+    if (g < count) for (int k = threadIdx.x; k < MTN; k += blockDim.x) states[(long)g * MTN + k] = base[k];
+}
+
+__device__ __forceinline__ uint32_t temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+constexpr int GT = 640;          // threads: [0,320) drive the U1 stream, [320,640) the U2 stream
+constexpr int HALF = 320;
+constexpr int KB = 4;            // MT blocks generated per consume batch
+constexpr int RING = 2048;       // doubles per stream kept between producer and consumer (> KB*313 + 313)
+constexpr int PFQ = (KB * 313 + GT - 1) / GT;   // A elements each thread prefetches per batch
+
+// H build with regenerated draws.  grid = (S sub-streams, G candidates): workgroup (b, g) builds the elements
+// [b*E, min((b+1)*E, n*n)) of candidate g from its own pair of generator states (the block-level
+// regeneration is barrier-bound, so the work is spread over G*S workgroups).
+__global__ void __launch_bounds__(GT)
+build_h_mt_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long strideH, c128* __restrict__ Hg,
+                  const c128* __restrict__ shift, const double* __restrict__ psi,
+                  int rhs_mode, const c128* __restrict__ X, long ldx, const int* __restrict__ slots,
+                  const c128* __restrict__ bvec,
+                  const uint32_t* __restrict__ states /* [G][S][2][624] */, const int* __restrict__ extra /* [G][S][2] */,
+                  const int* __restrict__ rpos /* [G][S][2] */, long E, int* __restrict__ flags)
+{
+    __shared__ uint32_t blk[2][2][MTN];      // [stream][parity][word]
+    __shared__ double ring[2][RING];
+    __shared__ long s_emitted[2];
+    const int g = blockIdx.y, sb = blockIdx.x, S = gridDim.x, tid = threadIdx.x;
+    const int s = tid / HALF, lt = tid - s * HALF;            // stream id, thread within the stream group
+    const long gi = ((long)g * S + sb) * 2;                   // index of this workgroup's first generator
+    c128* H = Hg + (long)g * strideH;
+    const c128 lam = shift[g];
+    const double ps = psi[g];
+    bool bad = false;
+
+    if (sb == 0) {
+        // pad rows / pad columns / augmented block (everything outside the n x n perturbation area)
+        for (long e = tid; e < (long)npad * (ldh - n); e += GT) {          // columns n..ldh of every row
+            const int i = (int)(e / (ldh - n)), j = n + (int)(e - (long)i * (ldh - n));
+            c128 v = cmake(0.0, 0.0);
+            if (j < npad) { if (i == j) v.x = 1.0; }
+            else if (j == npad && i < n) { v = (rhs_mode == 0) ? X[(long)slots[g] * ldx + i] : bvec[i]; bad |= !cfinite(v); }
+            H[(long)i * ldh + j] = v;
+        }
+        for (long e = tid; e < (long)(npad - n) * n; e += GT) {            // pad rows, columns 0..n
+            const int i = n + (int)(e / n), j = (int)(e - (long)(i - n) * n);
+            H[(long)i * ldh + j] = cmake(0.0, 0.0);
+        }
+    }
+
+    // bring each stream to its start block
+    {
+        const uint32_t* St = states + (gi + s) * MTN;
+        for (int k = lt; k < MTN; k += HALF) blk[s][0][k] = St[k];
+    }
+    __syncthreads();
+    const int ex0 = extra[gi], ex1 = extra[gi + 1];
+    const int exmax = max(ex0, ex1);
+    for (int it = 0; it < exmax; ++it) {       // both groups step together; a group that is done idles through the barriers
+        const int mine = (s == 0) ? ex0 : ex1;
+        const bool act = it < mine;
+        const uint32_t* od = blk[s][min(it, mine) & 1];
+        uint32_t* nw = blk[s][(min(it, mine) + 1) & 1];
+        if (act) for (int k = lt; k < MTD; k += HALF) nw[k] = od[k + MTM] ^ twist(od[k], od[k + 1]);
+        __syncthreads();
+        if (act) for (int k = MTD + lt; k < 2 * MTD; k += HALF) nw[k] = nw[k - MTD] ^ twist(od[k], od[k + 1]);
+        __syncthreads();
+        if (act) for (int k = 2 * MTD + lt; k < MTN; k += HALF) nw[k] = nw[k - MTD] ^ twist(od[k], (k == MTN - 1) ? nw[0] : od[k + 1]);
+        __syncthreads();
+    }
+    int cur = ((s == 0) ? ex0 : ex1) & 1;            // parity slot holding this stream's current block
+    int wpos = rpos[gi + s];                         // next unread word of the current block (0..623)
+    const long e0 = (long)sb * E;
+    const long total = min((long)n * n, e0 + E);     // this workgroup's element range is [e0, total)
+    long emitted = e0;                               // absolute index of the next double this stream produces
+    long done = e0;
+    // a double = words (t, t+1); a pair may straddle two blocks when the stream starts at an odd position
+    while (done < total) {
+        // A values of the elements this batch will finish, requested before the generation work hides their latency
+        c128 apf[PFQ];
+#pragma unroll
+        for (int q = 0; q < PFQ; ++q) {
+            const long e = done + tid + (long)q * GT;
+            apf[q] = (e < total) ? A[e] : cmake(0.0, 0.0);
+        }
+        for (int bi = 0; bi < KB; ++bi) {
+            // ---- produce: all doubles whose second word lies in the current block ----
+            {
+                const uint32_t* cb = blk[s][cur];
+                const uint32_t* pb = blk[s][cur ^ 1];
+                const int first = wpos;                                   // -1: the pair started on the previous block's last word
+                const int npairs = (MTN - first) / 2;
+                for (int q = lt; q < npairs; q += HALF) {
+                    const int t = first + 2 * q;
+                    const uint32_t a = temper(t >= 0 ? cb[t] : pb[MTN - 1]) >> 5, b = temper(cb[t + 1]) >> 6;
+                    const long e = emitted + q;
+                    if (e < total) ring[s][e & (RING - 1)] = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+                }
+                emitted += npairs;
+                wpos = ((MTN - first) & 1) ? -1 : 0;
+            }
+            __syncthreads();
+            // ---- next block of each stream ----
+            {
+                const uint32_t* od = blk[s][cur];
+                uint32_t* nw = blk[s][cur ^ 1];
+                for (int k = lt; k < MTD; k += HALF) nw[k] = od[k + MTM] ^ twist(od[k], od[k + 1]);
+                __syncthreads();
+                for (int k = MTD + lt; k < 2 * MTD; k += HALF) nw[k] = nw[k - MTD] ^ twist(od[k], od[k + 1]);
+                __syncthreads();
+                for (int k = 2 * MTD + lt; k < MTN; k += HALF) nw[k] = nw[k - MTD] ^ twist(od[k], (k == MTN - 1) ? nw[0] : od[k + 1]);
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+        if (lt == 0) s_emitted[s] = emitted;
+        __syncthreads();
+        // ---- consume: elements both streams have produced (at most KB*313 <= PFQ*GT of them) ----
+        const long hi = min(min(s_emitted[0], s_emitted[1]), total);
+#pragma unroll
+        for (int q = 0; q < PFQ; ++q) {
+            const long e = done + tid + (long)q * GT;
+            if (e < hi) {
+                const int i = (int)(e / n), j = (int)(e - (long)i * n);
+                const c128 a = apf[q];
+                const double pr = __dmul_rn(__dmul_rn(__dsub_rn(ring[0][e & (RING - 1)], 0.5), ps), 0.15);
+                const double pi = __dmul_rn(__dmul_rn(__dsub_rn(ring[1][e & (RING - 1)], 0.5), ps), 0.15);
+                c128 h;
+                if (j == i) {
+                    h.x = __dadd_rn(__dsub_rn(a.x, lam.x), __dadd_rn(ps, pr));
+                    h.y = __dadd_rn(__dsub_rn(a.y, lam.y), __dadd_rn(0.0, pi));
+                } else {
+                    h.x = __dadd_rn(a.x, pr);
+                    h.y = __dadd_rn(a.y, pi);
+                }
+                bad |= !cfinite(h);
+                H[(long)i * ldh + j] = h;
+            }
+        }
+        done = hi;
+        __syncthreads();          // ring slots of this batch may be overwritten from here on
+    }
+    if (__any(bad) && (tid & 63) == 0) atomicOr(&flags[g], 1);
+}
+
+}  // namespace
+
+void maus_mt_copy_states(hipStream_t st, uint32_t* states, const uint32_t* base, int count) {
+    hipLaunchKernelGGL(mt_copy_state_kernel, dim3(count), dim3(256), 0, st, states, base, count);
+}
+int maus_mt_zero_tap() { return ZTAP; }
+void maus_mt_jump(hipStream_t st, uint32_t* states, const int* sel, int nsel, const int* taps, int ntap16) {
+    if (nsel > 0) hipLaunchKernelGGL(mt_jump_kernel, dim3(nsel), dim3(JT), 0, st, states, sel, taps, ntap16);
+}
+void maus_build_h_mt(hipStream_t st, const c128* A, int n, int npad, long ldh, long strideH, c128* H, int G, int S, long E,
+                     const c128* d_shift, const double* d_psi, int rhs_mode, const c128* X, long ldx, const int* d_slots,
+                     const c128* bvec, const uint32_t* states, const int* extra, const int* rpos, int* flags) {
+    hipLaunchKernelGGL(build_h_mt_kernel, dim3(S, G), dim3(GT), 0, st, A, n, npad, ldh, strideH, H, d_shift, d_psi, rhs_mode,
+                       X, ldx, d_slots, bvec, states, extra, rpos, E, flags);
+}

@@ -27,7 +27,7 @@ import weakref
 import numpy as np
 
 from . import _cabi
-from ._cabi import KIND_EIG, KIND_LINEAR, KIND_SVD, PERT_NONE, PERT_UNIFORM, POP_U, POP_W, POP_X
+from ._cabi import KIND_EIG, KIND_LINEAR, KIND_SVD, PERT_MT19937, PERT_NONE, PERT_UNIFORM, POP_U, POP_W, POP_X
 
 # reference constants (AMS:16-26) used by the step
 PSI_EPSILON_BASE = np.complex128(1e-20)
@@ -88,7 +88,7 @@ class DeviceEngine:
                  comm=None, ctx=None):
         self.ctx = ctx if ctx is not None else _cabi.Context(device)
         self._owner = {}                        # id(candidate) -> rank that executes it this step
-        self.pert_mode = pert_mode              # 'auto' | 'uniform' | 'none'
+        self.pert_mode = pert_mode              # 'auto' | 'uniform' | 'mt19937' | 'none'
         self.gmres_compat = gmres_compat        # 'rtol' | 'scipy-legacy'  
         self.comm = comm                        # dist.PopulationComm or None
         self._bound = None                      # matrix object currently on the device
@@ -173,7 +173,11 @@ class DeviceEngine:
             return PERT_UNIFORM
         if self.pert_mode == "none":
             return PERT_NONE
-        return PERT_UNIFORM if n <= 256 else PERT_NONE
+        if self.pert_mode == "mt19937":
+            return PERT_MT19937
+        # auto: small problems upload the exact host draws; large ones regenerate the same draws on the
+        # device from the NumPy state (bit-identical H either way)
+        return PERT_UNIFORM if n <= 256 else PERT_MT19937
 
     # ======================================================================================
     # device phases, sharded over ranks when a communicator is present (dist.py)
@@ -213,8 +217,12 @@ class DeviceEngine:
                                              pert_mode=pert, pert_data=pert_data)
         loc = np.zeros((len(mine), 1))
         if mine:
+            if pert == PERT_MT19937:
+                sub = (pert_data[0], pert_data[1], pert_data[2], np.asarray(pert_data[3])[mine])
+            else:
+                sub = None if pert_data is None else pert_data[mine]
             st = self.ctx.shifted_lu_solve([cands[k]._slot for k in mine], shift[mine], psi[mine], rhs_mode=rhs_mode,
-                                           pert_mode=pert, pert_data=None if pert_data is None else pert_data[mine])
+                                           pert_mode=pert, pert_data=sub)
             loc = st.astype(np.float64)[:, None]
         return self._exchange(cands, loc)[:, 0].astype(np.int32)
 
@@ -495,6 +503,9 @@ class DeviceEngine:
                     pert_data[k, 1] = np.random.rand(n, n)
                     rng_after.append(np.random.get_state())
             per_cand_words = words * (2 if legacy_gmres else 1)
+            if pert == PERT_MT19937:
+                # candidate k of the run uses the 4N^2 words at lead + k*per_cand_words of the current stream
+                pert_data = (rng_start, per_cand_words, per_cand_words - words, np.arange(len(run), dtype=np.int32))
             ahead = None
             if pert != PERT_UNIFORM and len(run) >= 8:
                 ahead = _AsyncStreamAdvance(per_cand_words * len(run))       # overlaps the GPU batch below
@@ -576,6 +587,8 @@ class DeviceEngine:
             pert_data[0, 0] = np.random.rand(n, n)                      # E3
             pert_data[0, 1] = np.random.rand(n, n)
         else:
+            if pert == PERT_MT19937:
+                pert_data = (np.random.get_state(), 4 * n * n, 0, np.zeros(1, dtype=np.int32))
             _advance_numpy_stream(4 * n * n)
         sh = np.array([shift], dtype=np.complex128)
         ps = np.array([psi.real if hasattr(psi, "real") else psi], dtype=np.float64)

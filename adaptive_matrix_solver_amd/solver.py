@@ -100,19 +100,20 @@ class InverseIterateSolver:
         while num_psi_attempts < self.max_attempts:                                    # AMS:43
             psi = self.base_psi_epsilon * (10 ** (num_psi_attempts / 2.0)) * (10 ** (candidate_stuck_counter / 3.0))
             pert_data = None
+            pmode = _cabi.PERT_UNIFORM if uniform else (_cabi.PERT_MT19937 if self.pert_mode == "mt19937" else _cabi.PERT_NONE)
             if uniform:
                 pert_data = np.empty((1, 2, n, n))
                 pert_data[0, 0] = np.random.rand(n, n)                                 # AMS:49
                 pert_data[0, 1] = np.random.rand(n, n)
             else:
+                if pmode == _cabi.PERT_MT19937:
+                    pert_data = (np.random.get_state(), 4 * n * n, 0, np.zeros(1, dtype=np.int32))
                 _advance_numpy_stream(4 * n * n)
             ps = np.array([complex(psi).real])
             rec = {"method": method, "attempt": num_psi_attempts, "psi": psi}
             try:
                 if method == "direct_solve":
-                    st = ctx.shifted_lu_solve([0], zero, ps, rhs_mode=1,
-                                              pert_mode=_cabi.PERT_UNIFORM if uniform else _cabi.PERT_NONE,
-                                              pert_data=pert_data)[0]
+                    st = ctx.shifted_lu_solve([0], zero, ps, rhs_mode=1, pert_mode=pmode, pert_data=pert_data)[0]
                     if st > 0:
                         raise np.linalg.LinAlgError("Matrix is singular.")
                     if st == -1:

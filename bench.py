@@ -164,7 +164,8 @@ def main():
                                    "direct-LU InverseIterateSolver path", "n": n, "pop": P,
                        "candidate_steps_timed": steps_done,
                        "parallelism": "A replicated, active candidates block-sharded over ranks, all-gather of records per phase",
-                       "pert_mode": "none(inert 0.15*psi term dropped; NumPy stream advanced by MT19937 jump)" if n > 256 else "uniform",
+                       "pert_mode": ("mt19937 (the reference's 2 x rand(N,N) draws per attempt regenerated bit-identically on the "
+                                     "device from the NumPy state)") if n > 256 else "uniform (host draws uploaded)",
                        "device": info["name"], "solver_build_s": round(t_build, 2)},
             "roofline": {"bound": "mfma", "kernel": "zgemm_kernel<64,64,16> (LU trailing updates, v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

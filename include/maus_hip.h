@@ -51,6 +51,17 @@ enum { MAUS_PERT_NONE = 0,      /* reg = psi*I only (the 0.15*psi random term is
        MAUS_PERT_MT19937 = 2 }; /* device regenerates the legacy NumPy MT19937 stream from a supplied
                                    624-word state per candidate (bit-identical draws)                    */
 
+/* MAUS_PERT_MT19937 descriptor: legacy NumPy RandomState (np.random.get_state()) + consumption pattern.
+ * words_per_candidate and lead_words must be multiples of 2*n*n (one rand(N,N) draw). */
+typedef struct {
+    uint32_t key[624];
+    int32_t pos;                    /* 0..624, as returned by get_state() */
+    int32_t reserved;
+    uint64_t words_per_candidate;   /* 4*n*n per dense attempt (8*n*n when a swallowed GMRES attempt draws first) */
+    uint64_t lead_words;            /* words each candidate skips before the draws it uses */
+    const int32_t* ordinals;        /* [count] position of each candidate in the run */
+} maus_mt_desc;
+
 /* ---- lifecycle ---------------------------------------------------------- */
 int maus_ctx_create(int device, maus_ctx** out);
 int maus_ctx_destroy(maus_ctx* ctx);
@@ -85,8 +96,9 @@ int maus_matvec_rayleigh(maus_ctx* ctx, const int* slots, int count, double* num
  * shift_c128[count] complex (0 for linear), psi[count] real.
  * pert: see MAUS_PERT_*; `pert_data` is
  *   UNIFORM: host double[count][2][n][n]   (U1 then U2 per candidate)
- *   MT19937: host uint32[count][625]       (624 key words + position; state at the
- *            start of the candidate's draws)
+ *   MT19937: host maus_mt_desc (below): the NumPy state at the start of the run and, per candidate,
+ *            its ordinal in the run; candidate i uses the 4*n*n words starting at
+ *            lead_words + ordinals[i] * words_per_candidate
  * status[count]: see conventions. */
 int maus_shifted_lu_solve(maus_ctx* ctx, const int* slots, int count, const double* shift_c128,
                           const double* psi, int rhs_mode, int pert_mode, const void* pert_data,

@@ -1,0 +1,98 @@
+"""Device-side regeneration of the legacy NumPy MT19937 draws (MAUS_PERT_MT19937): the H matrices built
+from a NumPy state on the device must be bit-identical to those built from the host's own
+np.random.rand(N,N) draws (MAUS_PERT_UNIFORM), so the LU solutions are bit-identical too (GPU only)."""
+import numpy as np
+import pytest
+
+import scenarios
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from adaptive_matrix_solver_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n,count,pre_bytes,legacy", [(33, 5, 0, False), (100, 7, 4, False), (256, 4, 12, True),
+                                                     (17, 3, 4, False), (8, 6, 0, False), (312, 3, 0, False), (640, 3, 4, False)])
+def test_mt19937_device_draws_equal_host_draws(ctx, n, count, pre_bytes, legacy):
+    from adaptive_matrix_solver_amd import _cabi
+    A = scenarios.ginibre(n, n + 1, 1.0)
+    ctx.set_matrix(A)
+    ctx.pop_reserve(count)
+    rng = np.random.default_rng(n)
+    V = rng.standard_normal((count, n)) + 1j * rng.standard_normal((count, n))
+    slots = list(range(count))
+    shift = (rng.standard_normal(count) + 1j * rng.standard_normal(count)) * 0.2
+    psi = np.full(count, 1e-3)                     # large enough that every draw changes H visibly
+    np.random.seed(1000 + n)
+    np.random.rand(777)                            # arbitrary stream position
+    if pre_bytes:
+        np.random.bytes(pre_bytes)                 # odd word position: doubles straddle block boundaries
+    start = np.random.get_state()
+    # host draws, exactly as the reference consumes them (a swallowed GMRES attempt draws one pair first)
+    U = np.empty((count, 2, n, n))
+    for k in range(count):
+        if legacy:
+            np.random.rand(n, n); np.random.rand(n, n)
+        U[k, 0] = np.random.rand(n, n)
+        U[k, 1] = np.random.rand(n, n)
+    end_host = np.random.get_state()
+    ctx.pop_put(0, slots, V)
+    st1 = ctx.shifted_lu_solve(slots, shift, psi, pert_mode=_cabi.PERT_UNIFORM, pert_data=U)
+    W1 = ctx.pop_get(2, slots, n)
+    wpc = 4 * n * n * (2 if legacy else 1)
+    lead = wpc - 4 * n * n
+    ctx.pop_put(0, slots, V)
+    st2 = ctx.shifted_lu_solve(slots, shift, psi, pert_mode=_cabi.PERT_MT19937,
+                               pert_data=(start, wpc, lead, np.arange(count, dtype=np.int32)))
+    W2 = ctx.pop_get(2, slots, n)
+    assert np.all(st1 == 0) and np.all(st2 == 0)
+    assert np.array_equal(W1, W2), "device-regenerated draws differ from np.random.rand"
+    # and the host-side jump lands exactly where the host draws left the stream
+    key, pos = _cabi.mt19937_jump(start[1], start[2], wpc * count)
+    assert np.array_equal(key, end_host[1]) and pos == end_host[2]
+    # perturbation really matters at this psi (guards against both paths silently dropping it)
+    ctx.pop_put(0, slots, V)
+    ctx.shifted_lu_solve(slots, shift, psi, pert_mode=_cabi.PERT_NONE)
+    W0 = ctx.pop_get(2, slots, n)
+    assert not np.allclose(W0, W1, rtol=1e-9, atol=0)
+
+
+def test_sharded_ordinals_pick_the_right_substreams(ctx):
+    """A rank that owns only some candidates of the run regenerates exactly their draws."""
+    from adaptive_matrix_solver_amd import _cabi
+    n, count = 64, 9
+    A = scenarios.ginibre(n, 5, 1.0)
+    ctx.set_matrix(A)
+    ctx.pop_reserve(count)
+    rng = np.random.default_rng(3)
+    V = rng.standard_normal((count, n)) + 1j * rng.standard_normal((count, n))
+    shift = np.zeros(count, dtype=np.complex128)
+    psi = np.full(count, 1e-2)
+    np.random.seed(5)
+    start = np.random.get_state()
+    slots = list(range(count))
+    ctx.pop_put(0, slots, V)
+    ctx.shifted_lu_solve(slots, shift, psi, pert_mode=_cabi.PERT_MT19937,
+                         pert_data=(start, 4 * n * n, 0, np.arange(count, dtype=np.int32)))
+    Wall = ctx.pop_get(2, slots, n)
+    mine = [2, 3, 7]
+    ctx.pop_put(0, slots, V)
+    ctx.shifted_lu_solve(mine, shift[mine], psi[mine], pert_mode=_cabi.PERT_MT19937,
+                         pert_data=(start, 4 * n * n, 0, np.array(mine, dtype=np.int32)))
+    Wsub = ctx.pop_get(2, mine, n)
+    assert np.array_equal(Wsub, Wall[mine])
+
+
+@pytest.mark.parametrize("name,iters", [("eig64", 8), ("eig48u", 8), ("lin32f", 6)])
+def test_trajectory_with_device_draws(name, iters):
+    """Whole loop bodies with pert_mode='mt19937' against the oracle: same bar as the uploaded-draws mode."""
+    from test_gpu_step_parity import compare, oracle_run, product_run
+    ref, anorm = oracle_run(name, iters)
+    got = product_run(name, iters, pert_mode="mt19937", gmres_compat="scipy-legacy")
+    compare(ref, got, anorm, name + "-mt19937")
