@@ -261,8 +261,9 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     if (c->H) fr += c->Hbytes;
     int gmax = (int)std::max<size_t>(1, (size_t)(fr * 0.80) / per);
     const char* env = getenv("MAUS_LU_BATCH");
-    int cap = env ? std::max(1, atoi(env)) : 256;
-    int G = std::min(std::min(want, cap), gmax);
+    int cap = env ? std::max(1, atoi(env)) : 512;
+    // head room: the population grows by a few spawned candidates per iteration, and re-allocating tens of GB costs seconds
+    int G = std::min(std::min(round_up(want + want / 4, 32), cap), gmax);
     if (c->H && c->Hnpad == npad && c->Hg >= G) return 0;
     HIPCHK(c, hipStreamSynchronize(c->st));
     if (c->H) { (void)hipFree(c->H); c->H = nullptr; }
@@ -291,7 +292,14 @@ static int ensure_lu_streams(maus_ctx* c, int n) {
     if (!c->ev_stage) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
     while ((int)c->lu_st.size() < n) {
         hipStream_t s; hipEvent_t e;
-        HIPCHK(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        // descending priorities keep the sub-batches out of phase: while the first one is in an MFMA-bound trailing
+        // update the next one gets the left-over issue slots for its bandwidth-bound panel / swap work, and vice versa
+        int plo = 0, phi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&plo, &phi);          // plo = least, phi = greatest (numerically lower)
+        const char* pe = getenv("MAUS_LU_PRIO");
+        const int idx = (int)c->lu_st.size();
+        int prio = (pe && atoi(pe) == 0) ? 0 : std::max(phi, std::min(plo, phi + idx));
+        HIPCHK(c, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
         HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->lu_st.push_back(s); c->lu_done.push_back(e);
     }

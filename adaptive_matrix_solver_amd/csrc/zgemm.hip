@@ -27,7 +27,7 @@
 
 namespace {
 
-template <int BM, int BN, int BK, int WM, int WN, int BLAY, bool CONJA, bool CONJB, bool PIPE, int MINW>
+template <int BM, int BN, int BK, int WM, int WN, int BLAY, bool CONJA, bool CONJB, bool PIPE, int MINW, bool M3 = false>
 __global__ void __launch_bounds__(64 * WM * WN, MINW)
 zgemm_kernel(int M, int N, int K,
              const c128* __restrict__ Ag, long lda, long strideA,
@@ -73,11 +73,16 @@ zgemm_kernel(int M, int N, int K,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
 
-    d4 cre[MB][NB], cim[MB][NB];
+    // 4M: cre / cim are the two result planes.  3M: cre = sum Are*Bre, cim = sum Aim*Bim,
+    // c3 = sum (Are+Aim)*(Bre+Bim); combined in the epilogue.
+    d4 cre[MB][NB], cim[MB][NB], c3[M3 ? MB : 1][M3 ? NB : 1];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { cre[i][j] = (d4){0, 0, 0, 0}; cim[i][j] = (d4){0, 0, 0, 0}; }
+        for (int j = 0; j < NB; ++j) {
+            cre[i][j] = (d4){0, 0, 0, 0}; cim[i][j] = (d4){0, 0, 0, 0};
+            if (M3) c3[i][j] = (d4){0, 0, 0, 0};
+        }
 
     c128 ra[A_PER], rb[B_PER];
 
@@ -158,7 +163,21 @@ zgemm_kernel(int M, int N, int K,
         for (int j = 0; j < NB; ++j) fb[slot][j] = Bs[krow * LDB_S + wn * WTN + j * 16 + (lane & 15)];
     };
     auto mfma_group = [&](int slot) {
-        {
+        if (M3) {
+            double as[MB], bs[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) as[i] = fa[slot][i].x + fa[slot][i].y;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bs[j] = fb[slot][j].x + fb[slot][j].y;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    cre[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][i].x, fb[slot][j].x, cre[i][j], 0, 0, 0);
+                    cim[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][i].y, fb[slot][j].y, cim[i][j], 0, 0, 0);
+                    c3[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[i], bs[j], c3[i][j], 0, 0, 0);
+                }
+        } else {
             // first products of every block (independent accumulators back to back) ...
 #pragma unroll
             for (int i = 0; i < MB; ++i)
@@ -236,7 +255,8 @@ zgemm_kernel(int M, int N, int K,
             for (int r = 0; r < 4; ++r) {
                 const int gm = m0 + wm * WTM + i * 16 + (lane >> 4) + 4 * r;
                 if (gm < M && gn < N) {
-                    const double vr = cre[i][j][r], vi = cim[i][j][r];
+                    const double vr = M3 ? cre[i][j][r] - cim[i][j][r] : cre[i][j][r];
+                    const double vi = M3 ? (c3[i][j][r] - cre[i][j][r]) - cim[i][j][r] : cim[i][j][r];
                     C[off[r]] = cmake(alpha * vr + cold[r].x, alpha * vi + cold[r].y);
                 }
             }
@@ -268,14 +288,14 @@ void launch_cfg(hipStream_t st, int M, int N, int K, const c128* A, long lda, lo
 }
 
 // plain-layout-only instantiation (LU trailing updates): one kernel per tile shape instead of eight
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, bool PIPE = false, int MINW = 4, bool M3 = false>
 void launch_lu_only(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA, const c128* B, long ldb, long sB,
                     c128* C, long ldc, long sC, double alpha, int beta, int batch, int, bool, bool,
                     const int* a_rows, const int* c_rows)
 {
     int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     int nwg = tiles_m * tiles_n;
-    hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WM, WN, 0, false, false, false, 4>), dim3(nwg, batch), dim3(64 * WM * WN), 0, st,
+    hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WM, WN, 0, false, false, PIPE, MINW, M3>), dim3(nwg, batch), dim3(64 * WM * WN), 0, st,
                        M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows);
 }
 
@@ -300,6 +320,25 @@ void maus_zgemm_launch_idx(hipStream_t st, int M, int N, int K, const c128* A, l
     if (cfg == 1 && M >= 128) { launch_cfg<128, 64, 16, 4, 2, true, 2>(ARGS); return; }   // reference: pipelined, 1 WG/CU
     // skinny shapes of the LU recursion (plain layout only): keep the 32x32 / 16x32 wave tile but shape
     // the workgroup tile like the problem so no MFMA runs on padding
+    // LU trailing updates (plain layout, both dimensions > 32): 3M complex product -- three real MFMA
+    // products per complex one (ArBr, AiBi, (Ar+Ai)(Br+Bi)) instead of four.  64x32 tiles with a 32x16
+    // wave tile keep the three accumulator planes inside 128 VGPRs, so four workgroups still share a CU.
+    // Measured (tools/gemm_cfg_check.py, K=256, 136 matrices): 76 TFLOP/s in 4M-equivalent flops against
+    // 66 for the 4M kernel; 64x64 (8 waves) 73, 32x64 75, 128x32 71, BK=32 72, pipelined 69.
+    // Error is normwise the same as 4M (measured 9.5e-16 vs 1.1e-15 relative on random data); the
+    // imaginary part loses the componentwise bound, which LU with partial pivoting does not rely on.
+    static const int use3m = [] { const char* e = getenv("MAUS_GEMM_3M"); return e ? atoi(e) : 1; }();
+    if (blay == 0 && !conja && !conjb && use3m && cfg == 0 && M > 32 && N > 32) {
+        launch_lu_only<64, 32, 16, 2, 2, false, 4, true>(ARGS); return;
+    }
+    if (blay == 0 && !conja && !conjb && cfg >= 3 && M > 32 && N > 32) {      // other measured 3M shapes
+        switch (cfg) {
+            case 3: launch_lu_only<64, 64, 16, 2, 4, false, 2, true>(ARGS); return;
+            case 5: launch_lu_only<128, 32, 16, 4, 2, false, 2, true>(ARGS); return;
+            case 8: launch_lu_only<32, 64, 16, 1, 4, false, 4, true>(ARGS); return;
+            default: break;
+        }
+    }
     if (blay == 0 && !conja && !conjb && cfg != 2) {
         if (N <= 16) { launch_lu_only<128, 16, 16, 4, 1>(ARGS); return; }
         if (N <= 32) { launch_lu_only<128, 32, 16, 4, 1>(ARGS); return; }
