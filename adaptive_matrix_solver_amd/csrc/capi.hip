@@ -624,8 +624,9 @@ int maus_zgemm_bench(maus_ctx* c, int M, int N, int K, int ld, int batch, int it
     c128* base = (c128*)c->scratch;
     if (getenv("MAUS_BENCH_ZERO")) { HIPCHK(c, hipMemsetAsync(base, 0, sizeof(c128) * per * batch, c->st)); }   // DVFS check
     else hipLaunchKernelGGL(fill_rand_kernel, dim3(2048), dim3(256), 0, c->st, (double*)base, per * batch * 2, 12345u);
+    const long sAB = getenv("MAUS_BENCH_SHARED_AB") ? 0 : (long)per;     // measurement aid: every matrix reads the same A and B
     auto launch = [&]() {
-        maus_zgemm_launch_idx(c->st, M, N, K, base + (size_t)K * ld, ld, (long)per, base + K, ld, (long)per,
+        maus_zgemm_launch_idx(c->st, M, N, K, base + (size_t)K * ld, ld, sAB, base + K, ld, sAB,
                               base + (size_t)K * ld + K, ld, (long)per, -1.0, 1, batch, 0, false, false, nullptr, nullptr);
     };
     launch();

@@ -16,7 +16,7 @@
 //   d[r] = D[row = (lane>>4) + 4r][col = lane&15].
 //
 // Tiling: BM x BN block tile, BK = 16, tiles staged through LDS as [k][m] / [k][n]
-// (k-major, +1 element row padding) so every fragment is one ds_read_b128 of an
+// (k-major, XOR-swizzled, see the kernel) so every fragment is one ds_read_b128 of an
 // interleaved (re,im) pair; the next K-tile is prefetched into registers while the
 // current one feeds the MFMAs.  The fp64 matrix pipe sustains 77.9 TFLOP/s with VGPR
 // accumulators (tools/probe_mfma_f64_v2; AGPR accumulators run at less than half of that),
@@ -39,7 +39,15 @@ zgemm_kernel(int M, int N, int K,
     constexpr int NT = 64 * WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
     constexpr int MB = WTM / 16, NB = WTN / 16;      // 16x16 blocks per wave
-    constexpr int LDA_S = BM + 1, LDB_S = BN + 1;    // LDS row strides (elements)
+    // LDS images are [k][m] / [k][n] with UNPADDED rows and the element index XOR-swizzled by (k & 7).
+    // ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (banks mod 64
+    // dwords): a fragment read (lanes 0-15 -> 16 consecutive elements of row k, lanes 16-31 -> row k+1) is
+    // conflict-free exactly when consecutive rows have the same bank alignment, i.e. without padding --
+    // the +1 padding used before cost 33 % extra LDS cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+    // ds_write_b128 is served in groups of 8 consecutive lanes (banks mod 32 dwords): the transposing
+    // A store (8 lanes = 8 consecutive k of one row) lands on 8 different 16-B columns through the XOR,
+    // which permutes inside aligned blocks of 8 and therefore keeps the reads conflict-free.
+    constexpr int LDA_S = BM, LDB_S = BN;            // LDS row strides (elements)
     constexpr int A_PER = BM * BK / NT, B_PER = BN * BK / NT;
     static_assert(A_PER * NT == BM * BK && B_PER * NT == BN * BK, "tile/threads mismatch");
 
@@ -104,23 +112,32 @@ zgemm_kernel(int M, int N, int K,
         if (BLAY == 0) { int gn = min(n0 + tid % BN, N - 1); pb[i] = B + gn; }
         else { int gn = min(n0 + tid / BK + i * (NT / BK), N - 1); pb[i] = B + (long)gn * ldb; }
     }
+    // plain layout: pb[i] points at this thread's B row for k0 = 0, so the per-tile step (k0 * ldb) is wave-uniform
+    if (BLAY == 0) {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) pb[i] += (long)(tid / BN + i * (NT / BN)) * ldb;
+    }
+    // The loads only LOAD: zeroing the K edge and conjugation happen when the registers are written to
+    // LDS one K-tile later.  (Touching the values here makes the compiler wait for the loads right away,
+    // which exposes the whole L2 latency in every K-tile: measured 76 -> 87 TFLOP/s on the 3M kernel.)
+    int kload = 0;                                   // k0 of the tile held in ra / rb
     auto load_tiles = [&](int k0) {
+        kload = k0;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int gk = k0 + (tid & (BK - 1));
-            c128 v = pa[i][KEDGE ? min(gk, K - 1) : gk];
-            if (KEDGE && gk >= K) v = cmake(0.0, 0.0);
-            if (CONJA) v.y = -v.y;
-            ra[i] = v;
+            ra[i] = pa[i][KEDGE ? min(gk, K - 1) : gk];
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
-            int gk = (BLAY == 0) ? k0 + tid / BN + i * (NT / BN) : k0 + (tid & (BK - 1));
-            int ck = KEDGE ? min(gk, K - 1) : gk;
-            c128 v = (BLAY == 0) ? pb[i][(long)ck * ldb] : pb[i][ck];
-            if (KEDGE && gk >= K) v = cmake(0.0, 0.0);
-            if (CONJB) v.y = -v.y;
-            rb[i] = v;
+            if (BLAY == 0) {
+                const int kr = tid / BN + i * (NT / BN);
+                if (!KEDGE) rb[i] = pb[i][(long)k0 * ldb];
+                else rb[i] = pb[i][(long)(min(k0 + kr, K - 1) - kr) * ldb];
+            } else {
+                int gk = k0 + (tid & (BK - 1));
+                rb[i] = pb[i][KEDGE ? min(gk, K - 1) : gk];
+            }
         }
     };
     auto store_tiles = [&](int buf) {
@@ -129,19 +146,28 @@ zgemm_kernel(int M, int N, int K,
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int k = tid & (BK - 1), r = tid / BK + i * (NT / BK);
-            As[k * LDA_S + r] = ra[i];
+            c128 v = ra[i];
+            if (KEDGE && kload + k >= K) v = cmake(0.0, 0.0);
+            if (CONJA) v.y = -v.y;
+            As[k * LDA_S + (r ^ (k & 7))] = v;
         }
         if (BLAY == 0) {
 #pragma unroll
             for (int i = 0; i < B_PER; ++i) {
                 int n = tid % BN, k = tid / BN + i * (NT / BN);
-                Bs[k * LDB_S + n] = rb[i];
+                c128 v = rb[i];
+                if (KEDGE && kload + k >= K) v = cmake(0.0, 0.0);
+                if (CONJB) v.y = -v.y;
+                Bs[k * LDB_S + (n ^ (k & 7))] = v;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < B_PER; ++i) {
                 int k = tid & (BK - 1), r = tid / BK + i * (NT / BK);
-                Bs[k * LDB_S + r] = rb[i];
+                c128 v = rb[i];
+                if (KEDGE && kload + k >= K) v = cmake(0.0, 0.0);
+                if (CONJB) v.y = -v.y;
+                Bs[k * LDB_S + (r ^ (k & 7))] = v;
             }
         }
     };
@@ -158,9 +184,9 @@ zgemm_kernel(int M, int N, int K,
         const c128* Bs = As + BK * LDA_S;
         const int krow = kk * 4 + (lane >> 4);
 #pragma unroll
-        for (int i = 0; i < MB; ++i) fa[slot][i] = As[krow * LDA_S + wm * WTM + i * 16 + (lane & 15)];
+        for (int i = 0; i < MB; ++i) fa[slot][i] = As[krow * LDA_S + ((wm * WTM + i * 16 + (lane & 15)) ^ (krow & 7))];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) fb[slot][j] = Bs[krow * LDB_S + wn * WTN + j * 16 + (lane & 15)];
+        for (int j = 0; j < NB; ++j) fb[slot][j] = Bs[krow * LDB_S + ((wn * WTN + j * 16 + (lane & 15)) ^ (krow & 7))];
     };
     auto mfma_group = [&](int slot) {
         if (M3) {
@@ -311,41 +337,37 @@ void maus_zgemm_launch_idx(hipStream_t st, int M, int N, int K, const c128* A, l
 {
     if (M <= 0 || N <= 0 || batch <= 0) return;
     static const int cfg = [] { const char* e = getenv("MAUS_GEMM_CFG"); return e ? atoi(e) : 0; }();
-#define ARGS st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, batch, blay, conja, conjb, a_rows, c_rows
-    // Default: 64x64 tiles, 4 waves per workgroup, <= 128 VGPRs and 33 KB of LDS so that FOUR independent
-    // workgroups share a CU (4 waves per SIMD).  Measured on MI355X (tools/gemm_sweep*.py, K=256, 136
-    // matrices): 66 TFLOP/s, against 50-55 for every one-workgroup-per-CU variant (128x64 / 128x128
-    // tiles, BK 16/32, with or without the software-pipelined loop): with both waves of a SIMD in
-    // the same workgroup they run in lockstep and every wait or barrier of one is a bubble for both.
-    if (cfg == 1 && M >= 128) { launch_cfg<128, 64, 16, 4, 2, true, 2>(ARGS); return; }   // reference: pipelined, 1 WG/CU
-    // skinny shapes of the LU recursion (plain layout only): keep the 32x32 / 16x32 wave tile but shape
-    // the workgroup tile like the problem so no MFMA runs on padding
-    // LU trailing updates (plain layout, both dimensions > 32): 3M complex product -- three real MFMA
-    // products per complex one (ArBr, AiBi, (Ar+Ai)(Br+Bi)) instead of four.  64x32 tiles with a 32x16
-    // wave tile keep the three accumulator planes inside 128 VGPRs, so four workgroups still share a CU.
-    // Measured (tools/gemm_cfg_check.py, K=256, 136 matrices): 76 TFLOP/s in 4M-equivalent flops against
-    // 66 for the 4M kernel; 64x64 (8 waves) 73, 32x64 75, 128x32 71, BK=32 72, pipelined 69.
-    // Error is normwise the same as 4M (measured 9.5e-16 vs 1.1e-15 relative on random data); the
-    // imaginary part loses the componentwise bound, which LU with partial pivoting does not rely on.
     static const int use3m = [] { const char* e = getenv("MAUS_GEMM_3M"); return e ? atoi(e) : 1; }();
-    if (blay == 0 && !conja && !conjb && use3m && cfg == 0 && M > 32 && N > 32) {
-        launch_lu_only<64, 32, 16, 2, 2, false, 4, true>(ARGS); return;
-    }
-    if (blay == 0 && !conja && !conjb && cfg >= 3 && M > 32 && N > 32) {      // other measured 3M shapes
-        switch (cfg) {
-            case 3: launch_lu_only<64, 64, 16, 2, 4, false, 2, true>(ARGS); return;
-            case 5: launch_lu_only<128, 32, 16, 4, 2, false, 2, true>(ARGS); return;
-            case 8: launch_lu_only<32, 64, 16, 1, 4, false, 4, true>(ARGS); return;
-            default: break;
-        }
-    }
+#define ARGS st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, batch, blay, conja, conjb, a_rows, c_rows
+    // All kernels: 4 waves per workgroup and registers / LDS small enough for 3-4 INDEPENDENT workgroups per
+    // CU.  Measured on MI355X (tools/gemm_cfg_check.py, gemm_sweep*.py; K=256, 136 matrices, 4M-equivalent
+    // TFLOP/s): every one-workgroup-per-CU shape (128x64 / 128x128, BK 16/32, software-pipelined or not)
+    // stays at 50-59 -- with all waves of a SIMD in one workgroup they run in lockstep and every wait or
+    // barrier of one is a bubble for all; 8-wave workgroups lose to 4-wave ones at equal tile area.
+    if (cfg == 1 && M >= 128) { launch_cfg<128, 64, 16, 4, 2, true, 2>(ARGS); return; }   // reference: pipelined, 1 WG/CU
     if (blay == 0 && !conja && !conjb && cfg != 2) {
+        // LU trailing updates (plain layout).  Skinny shapes keep the workgroup tile shaped like the
+        // problem so that no MFMA runs on padding.
         if (N <= 16) { launch_lu_only<128, 16, 16, 4, 1>(ARGS); return; }
-        if (N <= 32) { launch_lu_only<128, 32, 16, 4, 1>(ARGS); return; }
-        if (M <= 16) { launch_lu_only<16, 128, 16, 1, 4>(ARGS); return; }
-        if (M <= 32) { launch_lu_only<32, 128, 16, 1, 4>(ARGS); return; }
+        if (M <= 16) { launch_lu_only<16, 128, 16, 1, 4, false, 3>(ARGS); return; }
+        if (use3m) {
+            // 3M complex product: three real MFMA products per complex one (ArBr, AiBi, (Ar+Ai)(Br+Bi))
+            // instead of four.  A 32x16 wave tile keeps the three accumulator planes, the fragments and the
+            // in-flight prefetch of the next K-tile inside 128 VGPRs, so four workgroups still share a CU:
+            // 77 TFLOP/s (4M-equivalent) against 66 for the 4M kernel; other 3M shapes: 64x64 (8 waves) 75,
+            // 32x64 74, 128x32 (8 waves) 71, BK=32 72, double-buffered LDS 57-72.
+            // Error is normwise the same as 4M (9.5e-16 vs 1.1e-15 relative on random data); the imaginary
+            // part loses its componentwise bound, which LU with partial pivoting does not rely on.
+            if (cfg == 3) { launch_lu_only<64, 64, 16, 2, 4, false, 2, true>(ARGS); return; }
+            if (M <= 32 || cfg == 8) { launch_lu_only<32, 64, 16, 1, 4, false, 4, true>(ARGS); return; }
+            launch_lu_only<64, 32, 16, 2, 2, false, 4, true>(ARGS); return;
+        }
+        if (N <= 32) { launch_lu_only<128, 32, 16, 4, 1, false, 2>(ARGS); return; }
+        if (M <= 32) { launch_lu_only<32, 128, 16, 1, 4, false, 2>(ARGS); return; }
     }
-    launch_cfg<64, 64, 16, 2, 2, false, 4>(ARGS);
+    // 4M (population matvecs, Hermitian / SVD products, MAUS_GEMM_3M=0): 64x64 tiles, 32x32 wave tile.
+    // With the next K-tile genuinely in flight during the MFMAs this needs ~160 VGPRs: three workgroups per CU.
+    launch_cfg<64, 64, 16, 2, 2, false, 3>(ARGS);
 #undef ARGS
 }
 
