@@ -45,7 +45,7 @@ int maus_gmres_run(maus_ctx* ctx, const int* slots, int count, const double* shi
 int maus_jacobi_check_run(maus_ctx* ctx, int count, const double* shift, const double* psi, int32_t* ok);
 
 // ---- context ---------------------------------------------------------------------------
-struct ProfRec { int klass; hipEvent_t e0, e1; double flops, bytes; };
+struct ProfRec { int klass; hipEvent_t e0, e1; double flops, bytes, weight; };
 
 struct maus_ctx {
     int device = 0;
@@ -80,6 +80,7 @@ struct maus_ctx {
     bool prof_on = false;
     int prof_mode = 1;            // 1: every launch of every class; 2: every 5th launch of the zgemm classes only
     long prof_seq = 0; bool prof_skip = false;
+    long prof_cnt[KC_COUNT] = {0}; int prof_stride_big = 5, prof_stride_small = 0; double prof_weight = 1.0;
     int total_launches[KC_COUNT] = {0};
     std::vector<ProfRec> pending;
     std::vector<hipEvent_t> pool;

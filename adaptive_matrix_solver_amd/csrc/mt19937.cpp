@@ -180,6 +180,23 @@ void apply_poly(const Poly& g, uint32_t* s) {
     for (int k = 0; k < N; ++k) { int idx = h + k; if (idx >= N) idx -= N; s[k] = buf[idx]; }
 }
 
+// g = x^J mod phi through the cache.  The mutex covers only the lookups: a new polynomial takes tens of
+// milliseconds, and the engine's worker thread (whole-run advance) and the device path (lifting polynomials)
+// ask for different J concurrently.
+int cached_poly(uint64_t J, Poly& g) {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_phi_ok) { if (!init_phi()) return -2; g_phi_ok = true; }
+        auto it = g_cache.find(J);
+        if (it != g_cache.end()) { g = it->second; return 0; }
+    }
+    poly_pow_x(J, g);
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_cache.size() > 256) g_cache.clear();
+    g_cache[J] = g;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int maus_mt19937_jump(uint32_t* key, int32_t* pos, uint64_t nwords) {
@@ -194,16 +211,7 @@ extern "C" int maus_mt19937_jump(uint32_t* key, int32_t* pos, uint64_t nwords) {
     // low bits of word 0 that the 19937-bit state does not carry)
     const uint64_t J = (uint64_t)N * (qb - 1);
     Poly g;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (!g_phi_ok) { if (!init_phi()) return -2; g_phi_ok = true; }
-        auto it = g_cache.find(J);
-        if (it == g_cache.end()) {
-            poly_pow_x(J, g);
-            if (g_cache.size() > 64) g_cache.clear();
-            g_cache[J] = g;
-        } else g = it->second;
-    }
+    if (cached_poly(J, g)) return -2;
     apply_poly(g, key);
     regen(key);
     *pos = newpos;
@@ -213,14 +221,8 @@ extern "C" int maus_mt19937_jump(uint32_t* key, int32_t* pos, uint64_t nwords) {
 // x^J mod phi as 312 little-endian 64-bit words (bit i = coefficient of x^i); cached.  Used by the device-side
 // stream regeneration (mtdev.hip) for its binary-lifting jumps.
 int maus_mt_jump_poly(uint64_t J, uint64_t* out312) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_phi_ok) { if (!init_phi()) return -2; g_phi_ok = true; }
-    auto it = g_cache.find(J);
-    if (it == g_cache.end()) {
-        Poly g; poly_pow_x(J, g);
-        if (g_cache.size() > 256) g_cache.clear();
-        it = g_cache.emplace(J, g).first;
-    }
-    memcpy(out312, it->second.w, sizeof(uint64_t) * PW);
+    Poly g;
+    if (cached_poly(J, g)) return -2;
+    memcpy(out312, g.w, sizeof(uint64_t) * PW);
     return 0;
 }
