@@ -18,6 +18,8 @@
 //   * base panel: one workgroup per matrix, rows owned by threads, 4-column sub-blocks kept in
 //     registers; pivot rule = LAPACK izamax (max |re|+|im|, first index wins).
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 #include <climits>
 #include <cstdlib>
 
@@ -439,6 +441,10 @@ static void lu_gemm(const LuWs& w, int r0, int r1, int c0, int c1, int k0, int k
     int M = r1 - r0, N = c1 - c0, K = k1 - k0;
     if (M <= 0 || N <= 0 || K <= 0) return;
     const int kc = (K >= 256) ? KC_GEMM : (K >= 128) ? KC_GEMM_K128 : (K >= 64) ? KC_GEMM_K64 : (K >= 32) ? KC_GEMM_K32 : KC_GEMM_K16;
+    // MAUS_LU_TRACE=<file>: one line "M N K batch" per trailing-update launch, in launch order (lets a PMC pass
+    // attribute rocprofv3's per-dispatch counters to the K classes: tools/pmc_traffic.py)
+    static FILE* trace = [] { const char* e = getenv("MAUS_LU_TRACE"); return e ? fopen(e, "a") : (FILE*)nullptr; }();
+    if (trace) { fprintf(trace, "%d %d %d %d\n", M, N, K, w.G); fflush(trace); }
     prof(w, kc, 0);
     maus_zgemm_launch(w.st, M, N, K, w.H + (long)r0 * w.ldh + k0, w.ldh, w.strideH,
                       w.H + (long)k0 * w.ldh + c0, w.ldh, w.strideH,

@@ -166,13 +166,21 @@ def main():
         tot_ms = sum(v["ms"] for v in prof.values())
         achieved = (g["flops"] / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else 0.0
         per_launch_ms = g["ms"] / max(1, g["launches"])
-        # HBM bytes per zgemm launch from the committed PMC passes of this same command (rocprofv3 cannot
-        # be combined with the timed run; see profiles/r01_zgemm_pmc_traffic.json for the recipe)
+        # HBM bytes per K>=256 zgemm launch from the committed PMC passes (rocprofv3 --pmc cannot be combined with
+        # the timed run; profiles/r01_zgemm_pmc_traffic.json holds the recipe).  Those passes ran the step as ONE
+        # 271-matrix chunk on one stream; the timed region launches half-size sub-batches, so the measured bytes are
+        # scaled by the ratio of algorithmic bytes per launch (the traffic / algorithmic ratio is what carries over).
         traffic = None
+        traffic_note = None
         try:
             with open(os.path.join(ROOT, "profiles", "r01_zgemm_pmc_traffic.json")) as f:
-                if n == 4096 and P == 256 and world == 1:
-                    traffic = json.load(f)["hbm_bytes_per_launch"]
+                if n == 4096 and P == 256 and world == 1 and g["launches"] > 0:
+                    pm = json.load(f)
+                    ratio = pm["hbm_bytes_per_launch"] / pm["algorithmic_bytes_per_launch"]
+                    traffic = ratio * g["bytes"] / g["launches"]
+                    traffic_note = {"pmc_hbm_bytes_per_launch": pm["hbm_bytes_per_launch"],
+                                    "pmc_algorithmic_bytes_per_launch": pm["algorithmic_bytes_per_launch"],
+                                    "hbm_over_algorithmic": ratio, "source": "profiles/r01_zgemm_pmc_traffic.json"}
         except Exception:
             traffic = None
         out = {
@@ -191,7 +199,7 @@ def main():
                        "device": info["name"], "solver_build_s": round(t_build, 2)},
             "roofline": {"bound": "mfma", "kernel": "zgemm_kernel<64,32,16,3M>, K>=256 launches (LU trailing updates, v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_detail": traffic_note,
                          "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["launches"]),
                          "launches": g["launches"], "avg_launch_ms": per_launch_ms, "event_sampling": args.kernel_events,
                          "flops_per_launch": g["flops"] / max(1, g["launches"]),
