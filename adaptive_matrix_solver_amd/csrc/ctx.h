@@ -8,12 +8,7 @@
 #include <vector>
 
 // ---- kernels / drivers implemented in the other translation units ---------------------
-struct LuWs {
-    c128* H; long ldh; long strideH; int n; int npad; int G;
-    int* ipiv; int* info; int* flags;
-    hipStream_t st;
-    void (*tick)(void* ud, int klass, int phase, double flops, double bytes); void* ud;
-};
+#include "luws.h"
 void maus_lu_factor(const LuWs& w, int nbo);
 void maus_lu_backsolve(const LuWs& w, c128* Wpop, long ldw, const int* d_slots, c128* xout_dense);
 void maus_build_h(const LuWs& w, const c128* A, const c128* d_shift, const double* d_psi, int rhs_mode,

@@ -18,6 +18,7 @@
 //   * base panel: one workgroup per matrix, rows owned by threads, 4-column sub-blocks kept in
 //     registers; pivot rule = LAPACK izamax (max |re|+|im|, first index wins).
 #include "common.h"
+#include "luws.h"
 #include <cstdio>
 #include <cstdlib>
 #include <climits>
@@ -427,12 +428,6 @@ backsolve_kernel(const c128* __restrict__ Hg, long ld, long strideH, int n, int 
 // =======================================================================================
 // host-side drivers (device pointers, all batched over G matrices on stream st)
 // =======================================================================================
-struct LuWs {
-    c128* H; long ldh; long strideH; int n; int npad; int G;
-    int* ipiv; int* info; int* flags;
-    hipStream_t st;
-    void (*tick)(void* ud, int klass, int phase, double flops, double bytes); void* ud;   // profiling hooks (may be null)
-};
 
 static inline void prof(const LuWs& w, int klass, int phase, double flops = 0, double bytes = 0) { if (w.tick) w.tick(w.ud, klass, phase, flops, bytes); }
 
