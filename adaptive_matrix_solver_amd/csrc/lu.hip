@@ -324,6 +324,180 @@ lu_panel_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
 }
 
 // ---------------------------------------------------------------------------------------
+// Left-looking form of the panel kernel (default).  Same pivot rule and data ownership, but a 4-column
+// sub-block applies the updates of the EARLIER sub-blocks to its own columns while loading them
+//     R[r][c] = A[r][c0+c] - sum_{j<c0} L[r][j] * U[j][c0+c]
+// instead of every sub-block pushing a rank-4 update through memory into the columns to its right.
+// Per 16-wide panel that is 40 column reads + 16 column writes instead of 56 + 36, every row is read as one
+// contiguous piece of 64..256 bytes, and the MFMA rank-4 phase with its extra barriers is gone.
+//   (b') U[0:c0][c0:c0+4] = L00^-1 A[0:c0][c0:c0+4]   (unit-lower L00 of the finished sub-blocks, <= 12x12,
+//        forward substitution by one lane per column out of LDS)
+//   (c') row update above, U broadcast from LDS, L read from the row's own finished columns
+//   (d') the 4 pivot steps on the register sub-block, exactly as in lu_panel_kernel
+// ---------------------------------------------------------------------------------------
+template <int RPT>
+__global__ void __launch_bounds__(PT)
+lu_panel_ll_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
+                   int* __restrict__ ipiv_g, int npad, int* __restrict__ info_g)
+{
+    c128* P = Hg + (long)blockIdx.x * strideH + (long)j0 * ld + j0;
+    int* ipiv = ipiv_g + (long)blockIdx.x * npad + j0;
+
+    constexpr int LW = NBP - PW;                 // widest finished part (12 columns)
+    __shared__ c128 s_piv[PW];
+    __shared__ c128 s_old[PW];
+    __shared__ double s_val[PT / 64];
+    __shared__ int s_idx[PT / 64];
+    __shared__ c128 s_L00[LW][LW];
+    __shared__ c128 s_U[LW][PW];
+    __shared__ int s_info;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_info = 0;
+    c128 R[RPT][PW];
+
+#pragma unroll
+    for (int sb = 0; sb < NBP / PW; ++sb) {
+        const int c0 = sb * PW;
+        if (sb > 0) {
+            // (b') U block of this sub-block's columns above the diagonal block
+            for (int e = tid; e < c0 * c0; e += PT) { const int j = e / c0, i = e - j * c0; s_L00[j][i] = P[(long)j * ld + i]; }
+            for (int e = tid; e < c0 * PW; e += PT) { const int j = e / PW, c = e - j * PW; s_U[j][c] = P[(long)j * ld + c0 + c]; }
+            __syncthreads();
+            if (tid < PW) {
+                for (int j = 1; j < c0; ++j) {
+                    c128 u = s_U[j][tid];
+                    for (int i = 0; i < j; ++i) cfms(u, s_L00[j][i], s_U[i][tid]);
+                    s_U[j][tid] = u;
+                }
+                for (int j = 0; j < c0; ++j) P[(long)j * ld + c0 + tid] = s_U[j][tid];
+            }
+            __syncthreads();
+        }
+        // (c') load this thread's rows of the sub-block, bringing them up to date on the way
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = tid + k * PT;
+            if (r < m) {
+                const c128* row = P + (long)r * ld;
+                c128 nw[PW];
+#pragma unroll
+                for (int c = 0; c < PW; ++c) nw[c] = row[c0 + c];
+                if (sb > 0 && r >= c0) {
+                    // one finished sub-block (4 columns = 64 bytes of the row) at a time: 16 VGPRs of L in flight
+#pragma unroll
+                    for (int pb = 0; pb < LW / PW; ++pb) {
+                        if (pb < sb) {
+                            c128 l[PW];
+#pragma unroll
+                            for (int j = 0; j < PW; ++j) l[j] = row[pb * PW + j];
+#pragma unroll
+                            for (int j = 0; j < PW; ++j)
+#pragma unroll
+                                for (int c = 0; c < PW; ++c) cfms(nw[c], l[j], s_U[pb * PW + j][c]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < PW; ++c) R[k][c] = nw[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < PW; ++c) {
+            const int a = c0 + c;            // pivot position (panel-local row == column index)
+            // ---- pivot search: max |re|+|im| over rows >= a, first index wins ----
+            double best = -1.0; int bidx = INT_MAX;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = tid + k * PT;
+                if (r < m && r >= a) {
+                    double v = cabs1(R[k][c]);
+                    if (v > best) { best = v; bidx = r; }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                double ov = __shfl_xor(best, o, 64);
+                int oi = __shfl_xor(bidx, o, 64);
+                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            }
+            if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
+            __syncthreads();
+            best = s_val[0]; bidx = s_idx[0];
+#pragma unroll
+            for (int w = 1; w < PT / 64; ++w) {
+                double ov = s_val[w]; int oi = s_idx[w];
+                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            }
+            const int p = (bidx == INT_MAX) ? a : bidx;   // all-NaN column: no swap (input flagged non-finite)
+            // ---- publish pivot row / displaced row of the register sub-block ----
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = tid + k * PT;
+                if (r == p) {
+#pragma unroll
+                    for (int cc = 0; cc < PW; ++cc) s_piv[cc] = R[k][cc];
+                }
+                if (r == a && p != a) {
+#pragma unroll
+                    for (int cc = 0; cc < PW; ++cc) s_old[cc] = R[k][cc];
+                }
+            }
+            // the other 12 panel columns are swapped in memory: finished L columns to the left, raw (not yet
+            // updated) columns to the right -- their pending updates use the swapped L rows, so this commutes
+            if (p != a && tid < NBP && (tid < c0 || tid >= c0 + PW)) {
+                c128 x = P[(long)a * ld + tid], y = P[(long)p * ld + tid];
+                P[(long)a * ld + tid] = y; P[(long)p * ld + tid] = x;
+            }
+            if (tid == 0) ipiv[a] = j0 + p;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = tid + k * PT;
+                if (p != a) {
+                    if (r == a) {
+#pragma unroll
+                        for (int cc = 0; cc < PW; ++cc) R[k][cc] = s_piv[cc];
+                    } else if (r == p) {
+#pragma unroll
+                        for (int cc = 0; cc < PW; ++cc) R[k][cc] = s_old[cc];
+                    }
+                }
+            }
+            const c128 pv = s_piv[c];
+            const bool zero_piv = (pv.x == 0.0 && pv.y == 0.0);
+            if (zero_piv && tid == 0 && s_info == 0) s_info = j0 + a + 1;   // LAPACK info (1-based)
+            const c128 rinv = zero_piv ? cmake(1.0, 0.0) : crecip(pv);
+            c128 prow[PW];
+#pragma unroll
+            for (int cc = 0; cc < PW; ++cc) prow[cc] = s_piv[cc];
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = tid + k * PT;
+                if (r < m && r > a) {
+                    c128 l = cmul(R[k][c], rinv);
+                    R[k][c] = l;
+#pragma unroll
+                    for (int cc = c + 1; cc < PW; ++cc) cfms(R[k][cc], l, prow[cc]);
+                }
+            }
+            __syncthreads();   // s_piv / s_val are rewritten by the next column
+        }
+        // store the factored sub-block
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = tid + k * PT;
+            if (r < m) {
+#pragma unroll
+                for (int c = 0; c < PW; ++c) P[(long)r * ld + c0 + c] = R[k][c];
+            }
+        }
+        __syncthreads();       // the next sub-block reads these columns (and the rows it swapped) from memory
+    }
+    if (tid == 0 && s_info != 0 && info_g[blockIdx.x] == 0) info_g[blockIdx.x] = s_info;
+}
+
+// ---------------------------------------------------------------------------------------
 // Row interchanges ipiv[k1..k2) applied to columns [c_lo, c_hi); one thread per column.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -476,9 +650,13 @@ static void lu_panel(const LuWs& w, int j0) {
     dim3 grid(w.G), block(PT);
     int rpt = (m + PT - 1) / PT;
     static const int dbg = [] { const char* e = getenv("MAUS_PANEL_DBG"); return e ? atoi(e) : 0; }();   // timing experiments only
+    static const int ll = [] { const char* e = getenv("MAUS_PANEL_LL"); return e ? atoi(e) : 1; }();
 #define PANEL(R) hipLaunchKernelGGL((lu_panel_kernel<R>), grid, block, 0, w.st, w.H, w.ldh, w.strideH, j0, m, w.ipiv, w.npad, w.info, dbg)
-    if (rpt <= 1) PANEL(1); else if (rpt <= 2) PANEL(2); else if (rpt <= 4) PANEL(4); else PANEL(8);
+#define PANEL_LL(R) hipLaunchKernelGGL((lu_panel_ll_kernel<R>), grid, block, 0, w.st, w.H, w.ldh, w.strideH, j0, m, w.ipiv, w.npad, w.info)
+    if (ll) { if (rpt <= 1) PANEL_LL(1); else if (rpt <= 2) PANEL_LL(2); else if (rpt <= 4) PANEL_LL(4); else PANEL_LL(8); }
+    else { if (rpt <= 1) PANEL(1); else if (rpt <= 2) PANEL(2); else if (rpt <= 4) PANEL(4); else PANEL(8); }
 #undef PANEL
+#undef PANEL_LL
     prof(w, KC_PANEL, 1, 8.0 * m * NBP * NBP / 2 * w.G, 16.0 * m * NBP * 8 * w.G);
 }
 
