@@ -30,14 +30,29 @@ __device__ __forceinline__ uint32_t twist(uint32_t u, uint32_t v) {
     return (y >> 1) ^ ((y & 1u) ? MAG : 0u);
 }
 
-// next block `nw` from block `od` (both time-ordered in LDS); all threads of the block take part
+// Word k of the NEXT block from the CURRENT block `od` alone.  The reference recurrence (mt19937.cpp regen)
+//   new[k] = new[k-227] ^ tw(od[k], od[k+1])      (k >= 227; new[k+397-624])
+//   new[k] = od[k+397]  ^ tw(od[k], od[k+1])      (k <  227)
+// is substituted into itself, so the words of the second and third part do not wait for the first:
+//   227 <= k < 454:  new[k] = od[k+170] ^ tw(od[k-227], od[k-226]) ^ tw(od[k], od[k+1])
+//   454 <= k < 624:  new[k] = od[k-57]  ^ tw(od[k-454], od[k-453]) ^ tw(od[k-227], od[k-226]) ^ tw(od[k], od[k+1])
+// (for k = 623 the "od[k+1]" is new[0] = od[397] ^ tw(od[0], od[1])).  1-4 twists per word instead of one, and a
+// whole block costs ONE barrier instead of three: used where a block walk has nothing else to do between barriers
+// (the 33-block prologue of mt_jump_kernel, the start-up regenerations of the H build).
+__device__ __forceinline__ uint32_t next_word(const uint32_t* od, int k) {
+    if (k < MTD) return od[k + MTM] ^ twist(od[k], od[k + 1]);
+    if (k < 2 * MTD) return od[k + 170] ^ twist(od[k - MTD], od[k - MTD + 1]) ^ twist(od[k], od[k + 1]);
+    const uint32_t nxt = (k == MTN - 1) ? (od[MTM] ^ twist(od[0], od[1])) : od[k + 1];
+    return od[k - 57] ^ twist(od[k - 2 * MTD], od[k - 2 * MTD + 1]) ^ twist(od[k - MTD], od[k - MTD + 1]) ^ twist(od[k], nxt);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0): inside the H build that
+// drains the prefetched A loads and the H stores (HBM round trips) at every barrier of the generator loop.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// next block `nw` from block `od` (both time-ordered in LDS, distinct buffers); all `nthreads` threads take part
 __device__ __forceinline__ void regen_block(const uint32_t* od, uint32_t* nw, int tid, int nthreads) {
-    for (int k = tid; k < MTD; k += nthreads) nw[k] = od[k + MTM] ^ twist(od[k], od[k + 1]);
-    __syncthreads();
-    for (int k = MTD + tid; k < 2 * MTD; k += nthreads) nw[k] = nw[k - MTD] ^ twist(od[k], od[k + 1]);
-    __syncthreads();
-    for (int k = 2 * MTD + tid; k < MTN; k += nthreads)
-        nw[k] = nw[k - MTD] ^ twist(od[k], (k == MTN - 1) ? nw[0] : od[k + 1]);
+    for (int k = tid; k < MTN; k += nthreads) nw[k] = next_word(od, k);
     __syncthreads();
 }
 
@@ -86,7 +101,8 @@ __device__ __forceinline__ uint32_t temper(uint32_t y) {
 
 constexpr int GT = 640;          // threads: [0,320) drive the U1 stream, [320,640) the U2 stream
 constexpr int HALF = 320;
-constexpr int KB = 4;            // MT blocks generated per consume batch
+constexpr int KB = 4;            // MT blocks generated per consume batch (even: s_last alternates per block)
+static_assert(KB % 2 == 0, "s_last parity");
 constexpr int RING = 2048;       // doubles per stream kept between producer and consumer (> KB*313 + 313)
 constexpr int PFQ = (KB * 313 + GT - 1) / GT;   // A elements each thread prefetches per batch
 
@@ -104,6 +120,7 @@ build_h_mt_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long st
     __shared__ uint32_t blk[2][2][MTN];      // [stream][parity][word]
     __shared__ double ring[2][RING];
     __shared__ long s_emitted[2];
+    __shared__ uint32_t s_last[2][2];            // [stream][parity] last word of the block before the current one
     const int g = blockIdx.y, sb = blockIdx.x, S = gridDim.x, tid = threadIdx.x;
     const int s = tid / HALF, lt = tid - s * HALF;            // stream id, thread within the stream group
     const long gi = ((long)g * S + sb) * 2;                   // index of this workgroup's first generator
@@ -140,11 +157,7 @@ build_h_mt_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long st
         const bool act = it < mine;
         const uint32_t* od = blk[s][min(it, mine) & 1];
         uint32_t* nw = blk[s][(min(it, mine) + 1) & 1];
-        if (act) for (int k = lt; k < MTD; k += HALF) nw[k] = od[k + MTM] ^ twist(od[k], od[k + 1]);
-        __syncthreads();
-        if (act) for (int k = MTD + lt; k < 2 * MTD; k += HALF) nw[k] = nw[k - MTD] ^ twist(od[k], od[k + 1]);
-        __syncthreads();
-        if (act) for (int k = 2 * MTD + lt; k < MTN; k += HALF) nw[k] = nw[k - MTD] ^ twist(od[k], (k == MTN - 1) ? nw[0] : od[k + 1]);
+        if (act) for (int k = lt; k < MTN; k += HALF) nw[k] = next_word(od, k);
         __syncthreads();
     }
     int cur = ((s == 0) ? ex0 : ex1) & 1;            // parity slot holding this stream's current block
@@ -160,40 +173,42 @@ build_h_mt_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long st
 #pragma unroll
         for (int q = 0; q < PFQ; ++q) {
             const long e = done + tid + (long)q * GT;
-            apf[q] = (e < total) ? A[e] : cmake(0.0, 0.0);
+            apf[q] = A[min(e, total - 1)];        // clamped index, no select on the value: the load stays in flight
         }
         for (int bi = 0; bi < KB; ++bi) {
+            const uint32_t* cb = blk[s][cur];
+            uint32_t* nb = blk[s][cur ^ 1];                               // previous block, about to become the next one
             // ---- produce: all doubles whose second word lies in the current block ----
             {
-                const uint32_t* cb = blk[s][cur];
-                const uint32_t* pb = blk[s][cur ^ 1];
                 const int first = wpos;                                   // -1: the pair started on the previous block's last word
                 const int npairs = (MTN - first) / 2;
+                const uint32_t prev_last = s_last[s][bi & 1];             // (only read when first == -1)
                 for (int q = lt; q < npairs; q += HALF) {
                     const int t = first + 2 * q;
-                    const uint32_t a = temper(t >= 0 ? cb[t] : pb[MTN - 1]) >> 5, b = temper(cb[t + 1]) >> 6;
+                    const uint32_t a = temper(t >= 0 ? cb[t] : prev_last) >> 5, b = temper(cb[t + 1]) >> 6;
                     const long e = emitted + q;
                     if (e < total) ring[s][e & (RING - 1)] = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
                 }
                 emitted += npairs;
                 wpos = ((MTN - first) & 1) ? -1 : 0;
             }
-            __syncthreads();
-            // ---- next block of each stream ----
-            {
-                const uint32_t* od = blk[s][cur];
-                uint32_t* nw = blk[s][cur ^ 1];
-                for (int k = lt; k < MTD; k += HALF) nw[k] = od[k + MTM] ^ twist(od[k], od[k + 1]);
-                __syncthreads();
-                for (int k = MTD + lt; k < 2 * MTD; k += HALF) nw[k] = nw[k - MTD] ^ twist(od[k], od[k + 1]);
-                __syncthreads();
-                for (int k = 2 * MTD + lt; k < MTN; k += HALF) nw[k] = nw[k - MTD] ^ twist(od[k], (k == MTN - 1) ? nw[0] : od[k + 1]);
-                __syncthreads();
-                cur ^= 1;
-            }
+            // ---- next block of each stream, started in the same barrier interval as the produce pass (its first
+            //      part only reads the current block; the previous block's last word, which a straddling pair
+            //      needs, travels through s_last) ----
+            if (lt == 0) s_last[s][(bi + 1) & 1] = cb[MTN - 1];
+            // the three dependent parts of the block, one LDS-only barrier each.  (Computing every word from the
+            // current block alone -- next_word(), one barrier per block -- was measured too: 59.6 vs 52.9 ms per
+            // 271-matrix step; with cheap barriers the kernel is bound by its integer instructions, and the
+            // one-pass form executes 1.9x the twists.)
+            for (int k = lt; k < MTD; k += HALF) nb[k] = cb[k + MTM] ^ twist(cb[k], cb[k + 1]);
+            lds_barrier();
+            for (int k = MTD + lt; k < 2 * MTD; k += HALF) nb[k] = nb[k - MTD] ^ twist(cb[k], cb[k + 1]);
+            lds_barrier();
+            for (int k = 2 * MTD + lt; k < MTN; k += HALF) nb[k] = nb[k - MTD] ^ twist(cb[k], (k == MTN - 1) ? nb[0] : cb[k + 1]);
+            if (bi == KB - 1 && lt == 0) s_emitted[s] = emitted;
+            lds_barrier();
+            cur ^= 1;
         }
-        if (lt == 0) s_emitted[s] = emitted;
-        __syncthreads();
         // ---- consume: elements both streams have produced (at most KB*313 <= PFQ*GT of them) ----
         const long hi = min(min(s_emitted[0], s_emitted[1]), total);
 #pragma unroll
@@ -217,7 +232,7 @@ build_h_mt_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long st
             }
         }
         done = hi;
-        __syncthreads();          // ring slots of this batch may be overwritten from here on
+        lds_barrier();            // ring slots of this batch may be overwritten from here on
     }
     if (__any(bad) && (tid & 63) == 0) atomicOr(&flags[g], 1);
 }

@@ -355,7 +355,7 @@ void maus_zgemm_launch_idx(hipStream_t st, int M, int N, int K, const c128* A, l
             // instead of four.  A 32x16 wave tile keeps the three accumulator planes, the fragments and the
             // in-flight prefetch of the next K-tile inside 128 VGPRs, so four workgroups still share a CU:
             // 77 TFLOP/s (4M-equivalent) against 66 for the 4M kernel; other 3M shapes: 64x64 (8 waves) 75,
-            // 32x64 74, 128x32 (8 waves) 71, BK=32 72, double-buffered LDS 57-72.
+            // 32x64 74, 128x32 (8 waves) 71, BK=32 55-60 (with the prefetch really in flight), double-buffered LDS 57-72.
             // Error is normwise the same as 4M (9.5e-16 vs 1.1e-15 relative on random data); the imaginary
             // part loses its componentwise bound, which LU with partial pivoting does not rely on.
             if (cfg == 3) { launch_lu_only<64, 64, 16, 2, 4, false, 2, true>(ARGS); return; }
