@@ -58,6 +58,11 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e. for every global
+// load and STORE the wave has in flight; where only LDS data changes hands between the phases that is a needless
+// HBM round trip per barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // kernel classes for the profiling counters (maus_profile_read)

@@ -422,7 +422,7 @@ lu_panel_ll_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
                 if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
             }
             if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
-            __syncthreads();
+            lds_barrier();
             best = s_val[0]; bidx = s_idx[0];
 #pragma unroll
             for (int w = 1; w < PT / 64; ++w) {
@@ -450,7 +450,7 @@ lu_panel_ll_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
                 P[(long)a * ld + tid] = y; P[(long)p * ld + tid] = x;
             }
             if (tid == 0) ipiv[a] = j0 + p;
-            __syncthreads();
+            lds_barrier();         // only s_piv / s_old cross threads here; the swapped columns are re-read by their own thread
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 const int r = tid + k * PT;
@@ -481,7 +481,7 @@ lu_panel_ll_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
                     for (int cc = c + 1; cc < PW; ++cc) cfms(R[k][cc], l, prow[cc]);
                 }
             }
-            __syncthreads();   // s_piv / s_val are rewritten by the next column
+            lds_barrier();     // s_piv / s_val are rewritten by the next column
         }
         // store the factored sub-block
 #pragma unroll

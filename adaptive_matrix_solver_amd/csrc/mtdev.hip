@@ -46,10 +46,6 @@ __device__ __forceinline__ uint32_t next_word(const uint32_t* od, int k) {
     return od[k - 57] ^ twist(od[k - 2 * MTD], od[k - 2 * MTD + 1]) ^ twist(od[k - MTD], od[k - MTD + 1]) ^ twist(od[k], nxt);
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0): inside the H build that
-// drains the prefetched A loads and the H stores (HBM round trips) at every barrier of the generator loop.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // next block `nw` from block `od` (both time-ordered in LDS, distinct buffers); all `nthreads` threads take part
 __device__ __forceinline__ void regen_block(const uint32_t* od, uint32_t* nw, int tid, int nthreads) {
     for (int k = tid; k < MTN; k += nthreads) nw[k] = next_word(od, k);

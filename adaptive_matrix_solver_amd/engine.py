@@ -507,6 +507,7 @@ class DeviceEngine:
                 # candidate k of the run uses the 4N^2 words at lead + k*per_cand_words of the current stream
                 pert_data = (rng_start, per_cand_words, per_cand_words - words, np.arange(len(run), dtype=np.int32))
             ahead = None
+            fb = np.zeros(len(run), dtype=bool)         # candidates that took the batched direct-solver retry
             if pert != PERT_UNIFORM and len(run) >= 8:
                 ahead = _AsyncStreamAdvance(per_cand_words * len(run))       # overlaps the GPU batch below
             if first_method == DIRECT or legacy_gmres:
@@ -514,6 +515,21 @@ class DeviceEngine:
                 ok = status == 0
             else:
                 ok = self._gmres_batch(run, shift, psi0, stuck, is_eig)
+                if pert != PERT_UNIFORM and not ok.all():
+                    # AMS:99-103 in batch: a failed attempt 0 with the preferred (GMRES) method is retried with the
+                    # direct solver at the same attempt index.  For ill-conditioned ("Fragile") systems that is the
+                    # common case, not the exception -- one batched LU instead of one ladder per candidate.  The
+                    # retry draws its own rand(N,N) pair (E3), right after the pair of the candidate's GMRES attempt:
+                    # candidate k's first attempt sits at attempt slot k + (number of earlier fallbacks).
+                    F = np.nonzero(~ok)[0]
+                    slot0 = np.concatenate([[0], np.cumsum(1 + (~ok).astype(np.int64))])[:-1]
+                    pd = None
+                    if pert == PERT_MT19937:
+                        pd = (rng_start, words, 0, (slot0[F] + 1).astype(np.int32))
+                    st = self.d_lu_solve([run[k] for k in F], shift[F], psi0[F], 0 if is_eig else 1, pert, pd)
+                    fb[F] = True
+                    ok = ok.copy()
+                    ok[F] = st == 0
             bad = np.nonzero(~ok)[0]
             nb = int(bad[0]) if bad.size else len(run)
 
@@ -527,7 +543,7 @@ class DeviceEngine:
                     if tiny.size:
                         e4 = int(tiny[0])
             nvalid = nb if (e4 is None or pert != PERT_UNIFORM) else e4 + 1
-            clean = ahead is not None and nvalid == len(run) and e4 is None
+            clean = ahead is not None and nvalid == len(run) and e4 is None and not fb.any()
             if ahead is not None and not clean:
                 ahead.discard()
             # --- RNG replay + bookkeeping for the accepted candidates, in list order ---
@@ -537,7 +553,7 @@ class DeviceEngine:
             for k in range(nvalid):
                 c = run[k]
                 if pert != PERT_UNIFORM and not clean:
-                    pending_words += per_cand_words                     # E3
+                    pending_words += per_cand_words * (2 if fb[k] else 1)   # E3 (attempt 0, and its direct-solver retry)
                 c.local_psi_retries_needed = 0                          # attempts == 0 (AMS:278)
                 c._invalidate()
                 if is_eig and e4 is not None and (k == e4 or (pert != PERT_UNIFORM and not (nrm[k] > 1e-10))):
@@ -560,8 +576,8 @@ class DeviceEngine:
                 if pert == PERT_UNIFORM:
                     np.random.set_state(rng_after[nb])
                 else:
-                    _advance_numpy_stream(per_cand_words)
-                failed_method = DIRECT if (first_method == DIRECT or legacy_gmres) else GMRES
+                    _advance_numpy_stream(per_cand_words * (2 if fb[nb] else 1))
+                failed_method = DIRECT if (first_method == DIRECT or legacy_gmres or fb[nb]) else GMRES
                 self._ladder(c, shift[nb], base_psi, max_retries, pref, failed_method, is_eig, n, pert)
                 if pert == PERT_UNIFORM:
                     for cc in run[nb + 1:]:

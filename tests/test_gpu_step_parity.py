@@ -195,6 +195,16 @@ def test_linear_fragile_legacy_gmres():
     compare(ref, got, anorm, "lin32f")
 
 
+@pytest.mark.parametrize("pert_mode", ["uniform", "mt19937"])
+def test_linear_fragile_real_gmres(pert_mode):
+    """The same system with GMRES really running (tol->rtol): unpreconditioned GMRES exhausts its 50 x 20 iterations
+    on this spectrum, the reference falls back to LU at the same attempt index (AMS:99-103) and draws a second
+    rand(N,N) pair.  'uniform' takes the one-candidate-at-a-time ladder, 'mt19937' the batched fallback."""
+    ref, anorm = oracle_run("lin32f", 6, gmres_mode="rtol")
+    got = product_run("lin32f", 6, pert_mode=pert_mode, gmres_compat="rtol")
+    compare(ref, got, anorm, "lin32f-rtol-" + pert_mode)
+
+
 def test_nan_ladder():
     """NaN-poisoned matrix: every step is a total failure (26 solve attempts), STUCK x7 then RETIRED."""
     import random
