@@ -260,7 +260,7 @@ int maus_matvec_rayleigh(maus_ctx* c, const int* slots, int count, double* num, 
 
 static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     int npad = round_up(n, 32);
-    if (npad > maus_lu_max_npad()) FAIL(c, "direct LU path supports n <= 4096 in this build");
+    if (npad > maus_lu_max_npad()) FAIL(c, "direct LU path supports n <= 8192 in this build");
     size_t per = sizeof(c128) * (size_t)npad * (npad + 32);
     if (c->H && c->Hnpad == npad && c->Hg >= want) return 0;
     size_t fr = 0, tot = 0;

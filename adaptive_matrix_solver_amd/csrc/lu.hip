@@ -333,9 +333,11 @@ lu_panel_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
 //   (b') U[0:c0][c0:c0+4] = L00^-1 A[0:c0][c0:c0+4]   (unit-lower L00 of the finished sub-blocks, <= 12x12,
 //        forward substitution by one lane per column out of LDS)
 //   (c') row update above, U broadcast from LDS, L read from the row's own finished columns
-//   (d') the 4 pivot steps on the register sub-block, exactly as in lu_panel_kernel
+//   (d') the pivot steps on the register sub-block, exactly as in lu_panel_kernel
+// PWL = sub-block width: 4 columns with up to 8 rows per thread (m <= 4096), 2 columns with 16 rows per thread
+// (m <= 8192) -- the same 128 VGPRs of sub-block either way.
 // ---------------------------------------------------------------------------------------
-template <int RPT>
+template <int RPT, int PWL>
 __global__ void __launch_bounds__(PT)
 lu_panel_ll_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
                    int* __restrict__ ipiv_g, int npad, int* __restrict__ info_g)
@@ -343,28 +345,28 @@ lu_panel_ll_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
     c128* P = Hg + (long)blockIdx.x * strideH + (long)j0 * ld + j0;
     int* ipiv = ipiv_g + (long)blockIdx.x * npad + j0;
 
-    constexpr int LW = NBP - PW;                 // widest finished part (12 columns)
-    __shared__ c128 s_piv[PW];
-    __shared__ c128 s_old[PW];
+    constexpr int LW = NBP - PWL;                 // widest finished part (12 columns)
+    __shared__ c128 s_piv[PWL];
+    __shared__ c128 s_old[PWL];
     __shared__ double s_val[PT / 64];
     __shared__ int s_idx[PT / 64];
     __shared__ c128 s_L00[LW][LW];
-    __shared__ c128 s_U[LW][PW];
+    __shared__ c128 s_U[LW][PWL];
     __shared__ int s_info;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_info = 0;
-    c128 R[RPT][PW];
+    c128 R[RPT][PWL];
 
 #pragma unroll
-    for (int sb = 0; sb < NBP / PW; ++sb) {
-        const int c0 = sb * PW;
+    for (int sb = 0; sb < NBP / PWL; ++sb) {
+        const int c0 = sb * PWL;
         if (sb > 0) {
             // (b') U block of this sub-block's columns above the diagonal block
             for (int e = tid; e < c0 * c0; e += PT) { const int j = e / c0, i = e - j * c0; s_L00[j][i] = P[(long)j * ld + i]; }
-            for (int e = tid; e < c0 * PW; e += PT) { const int j = e / PW, c = e - j * PW; s_U[j][c] = P[(long)j * ld + c0 + c]; }
+            for (int e = tid; e < c0 * PWL; e += PT) { const int j = e / PWL, c = e - j * PWL; s_U[j][c] = P[(long)j * ld + c0 + c]; }
             __syncthreads();
-            if (tid < PW) {
+            if (tid < PWL) {
                 for (int j = 1; j < c0; ++j) {
                     c128 u = s_U[j][tid];
                     for (int i = 0; i < j; ++i) cfms(u, s_L00[j][i], s_U[i][tid]);
@@ -380,30 +382,30 @@ lu_panel_ll_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
             const int r = tid + k * PT;
             if (r < m) {
                 const c128* row = P + (long)r * ld;
-                c128 nw[PW];
+                c128 nw[PWL];
 #pragma unroll
-                for (int c = 0; c < PW; ++c) nw[c] = row[c0 + c];
+                for (int c = 0; c < PWL; ++c) nw[c] = row[c0 + c];
                 if (sb > 0 && r >= c0) {
                     // one finished sub-block (4 columns = 64 bytes of the row) at a time: 16 VGPRs of L in flight
 #pragma unroll
-                    for (int pb = 0; pb < LW / PW; ++pb) {
+                    for (int pb = 0; pb < LW / PWL; ++pb) {
                         if (pb < sb) {
-                            c128 l[PW];
+                            c128 l[PWL];
 #pragma unroll
-                            for (int j = 0; j < PW; ++j) l[j] = row[pb * PW + j];
+                            for (int j = 0; j < PWL; ++j) l[j] = row[pb * PWL + j];
 #pragma unroll
-                            for (int j = 0; j < PW; ++j)
+                            for (int j = 0; j < PWL; ++j)
 #pragma unroll
-                                for (int c = 0; c < PW; ++c) cfms(nw[c], l[j], s_U[pb * PW + j][c]);
+                                for (int c = 0; c < PWL; ++c) cfms(nw[c], l[j], s_U[pb * PWL + j][c]);
                         }
                     }
                 }
 #pragma unroll
-                for (int c = 0; c < PW; ++c) R[k][c] = nw[c];
+                for (int c = 0; c < PWL; ++c) R[k][c] = nw[c];
             }
         }
 #pragma unroll
-        for (int c = 0; c < PW; ++c) {
+        for (int c = 0; c < PWL; ++c) {
             const int a = c0 + c;            // pivot position (panel-local row == column index)
             // ---- pivot search: max |re|+|im| over rows >= a, first index wins ----
             double best = -1.0; int bidx = INT_MAX;
@@ -436,16 +438,16 @@ lu_panel_ll_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
                 const int r = tid + k * PT;
                 if (r == p) {
 #pragma unroll
-                    for (int cc = 0; cc < PW; ++cc) s_piv[cc] = R[k][cc];
+                    for (int cc = 0; cc < PWL; ++cc) s_piv[cc] = R[k][cc];
                 }
                 if (r == a && p != a) {
 #pragma unroll
-                    for (int cc = 0; cc < PW; ++cc) s_old[cc] = R[k][cc];
+                    for (int cc = 0; cc < PWL; ++cc) s_old[cc] = R[k][cc];
                 }
             }
             // the other 12 panel columns are swapped in memory: finished L columns to the left, raw (not yet
             // updated) columns to the right -- their pending updates use the swapped L rows, so this commutes
-            if (p != a && tid < NBP && (tid < c0 || tid >= c0 + PW)) {
+            if (p != a && tid < NBP && (tid < c0 || tid >= c0 + PWL)) {
                 c128 x = P[(long)a * ld + tid], y = P[(long)p * ld + tid];
                 P[(long)a * ld + tid] = y; P[(long)p * ld + tid] = x;
             }
@@ -457,10 +459,10 @@ lu_panel_ll_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
                 if (p != a) {
                     if (r == a) {
 #pragma unroll
-                        for (int cc = 0; cc < PW; ++cc) R[k][cc] = s_piv[cc];
+                        for (int cc = 0; cc < PWL; ++cc) R[k][cc] = s_piv[cc];
                     } else if (r == p) {
 #pragma unroll
-                        for (int cc = 0; cc < PW; ++cc) R[k][cc] = s_old[cc];
+                        for (int cc = 0; cc < PWL; ++cc) R[k][cc] = s_old[cc];
                     }
                 }
             }
@@ -468,9 +470,9 @@ lu_panel_ll_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
             const bool zero_piv = (pv.x == 0.0 && pv.y == 0.0);
             if (zero_piv && tid == 0 && s_info == 0) s_info = j0 + a + 1;   // LAPACK info (1-based)
             const c128 rinv = zero_piv ? cmake(1.0, 0.0) : crecip(pv);
-            c128 prow[PW];
+            c128 prow[PWL];
 #pragma unroll
-            for (int cc = 0; cc < PW; ++cc) prow[cc] = s_piv[cc];
+            for (int cc = 0; cc < PWL; ++cc) prow[cc] = s_piv[cc];
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 const int r = tid + k * PT;
@@ -478,7 +480,7 @@ lu_panel_ll_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
                     c128 l = cmul(R[k][c], rinv);
                     R[k][c] = l;
 #pragma unroll
-                    for (int cc = c + 1; cc < PW; ++cc) cfms(R[k][cc], l, prow[cc]);
+                    for (int cc = c + 1; cc < PWL; ++cc) cfms(R[k][cc], l, prow[cc]);
                 }
             }
             lds_barrier();     // s_piv / s_val are rewritten by the next column
@@ -489,7 +491,7 @@ lu_panel_ll_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
             const int r = tid + k * PT;
             if (r < m) {
 #pragma unroll
-                for (int c = 0; c < PW; ++c) P[(long)r * ld + c0 + c] = R[k][c];
+                for (int c = 0; c < PWL; ++c) P[(long)r * ld + c0 + c] = R[k][c];
             }
         }
         __syncthreads();       // the next sub-block reads these columns (and the rows it swapped) from memory
@@ -652,8 +654,11 @@ static void lu_panel(const LuWs& w, int j0) {
     static const int dbg = [] { const char* e = getenv("MAUS_PANEL_DBG"); return e ? atoi(e) : 0; }();   // timing experiments only
     static const int ll = [] { const char* e = getenv("MAUS_PANEL_LL"); return e ? atoi(e) : 1; }();
 #define PANEL(R) hipLaunchKernelGGL((lu_panel_kernel<R>), grid, block, 0, w.st, w.H, w.ldh, w.strideH, j0, m, w.ipiv, w.npad, w.info, dbg)
-#define PANEL_LL(R) hipLaunchKernelGGL((lu_panel_ll_kernel<R>), grid, block, 0, w.st, w.H, w.ldh, w.strideH, j0, m, w.ipiv, w.npad, w.info)
-    if (ll) { if (rpt <= 1) PANEL_LL(1); else if (rpt <= 2) PANEL_LL(2); else if (rpt <= 4) PANEL_LL(4); else PANEL_LL(8); }
+#define PANEL_LL(R, W) hipLaunchKernelGGL((lu_panel_ll_kernel<R, W>), grid, block, 0, w.st, w.H, w.ldh, w.strideH, j0, m, w.ipiv, w.npad, w.info)
+    if (ll || rpt > 8) {
+        if (rpt <= 1) PANEL_LL(1, 4); else if (rpt <= 2) PANEL_LL(2, 4); else if (rpt <= 4) PANEL_LL(4, 4);
+        else if (rpt <= 8) PANEL_LL(8, 4); else PANEL_LL(16, 2);
+    }
     else { if (rpt <= 1) PANEL(1); else if (rpt <= 2) PANEL(2); else if (rpt <= 4) PANEL(4); else PANEL(8); }
 #undef PANEL
 #undef PANEL_LL
@@ -672,7 +677,7 @@ static void lu_recurse(const LuWs& w, int j0, int wd) {
 }
 
 // Maximum rows the base panel can own (8 rows per thread x 512 threads)
-int maus_lu_max_npad() { return PT * 8; }
+int maus_lu_max_npad() { return PT * 16; }     // 16 rows per thread in the 2-column panel variant
 
 // Factor all G matrices in the workspace and carry the augmented column through (L y = P b).
 void maus_lu_factor(const LuWs& w, int nbo) {
@@ -690,8 +695,8 @@ void maus_lu_backsolve(const LuWs& w, c128* Wpop, long ldw, const int* d_slots, 
     prof(w, KC_BACKSOLVE, 0);
     size_t shm = sizeof(c128) * ((size_t)w.npad + BSB * (BSB + 1) + BSB);
     static bool attr_set = false;
-    if (!attr_set) {   // up to ~83 KB of dynamic LDS at npad = 4096 (160 KB per CU on gfx950)
-        (void)hipFuncSetAttribute((const void*)backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (!attr_set) {   // ~83 KB of dynamic LDS at npad = 4096, 145 KB at 8192 (160 KB per CU on gfx950)
+        (void)hipFuncSetAttribute((const void*)backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL(backsolve_kernel, dim3(w.G), dim3(1024), shm, w.st, w.H, w.ldh, w.strideH, w.n, w.npad,

@@ -218,6 +218,26 @@ def test_eig4096_loop_body_bookkeeping_and_stream():
         assert abs(np.linalg.norm(v) - 1.0) <= 1e-12
 
 
+def test_lu_beyond_4096_same_pivots_as_lapack(ctx):
+    """n = 5000: panels taller than 4096 rows take the 16-rows-per-thread / 2-column panel variant."""
+    import scipy.linalg as sla
+    n = 5000
+    rng = np.random.default_rng(50)
+    A = (rng.standard_normal((1, n, n)) + 1j * rng.standard_normal((1, n, n))) / np.sqrt(n)
+    b = rng.standard_normal((1, n)) + 1j * rng.standard_normal((1, n))
+    x, status, ipiv = ctx.lu_solve(A, b, want_ipiv=True)
+    assert status[0] == 0
+    lu, piv = sla.lu_factor(A[0])
+    assert np.array_equal(ipiv[0], piv)
+    ref = sla.lu_solve((lu, piv), b[0])
+    # backward error: no worse than a few times LAPACK's own on the same factorisation order
+    r_dev = np.linalg.norm(A[0] @ x[0] - b[0])
+    r_ref = np.linalg.norm(A[0] @ ref - b[0])
+    floor = np.finfo(float).eps * np.linalg.norm(A[0], 1) * np.linalg.norm(ref)
+    assert r_dev <= 10.0 * max(r_ref, floor), (r_dev, r_ref, floor)
+    assert np.linalg.norm(x[0] - ref) <= 1e-7 * np.linalg.norm(ref)
+
+
 # ---------------------------------------------------------------------------------------------
 # configs[2]: 4096 x 4096 linear system, GMRES + Jacobi
 # ---------------------------------------------------------------------------------------------
