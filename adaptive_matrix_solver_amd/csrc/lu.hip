@@ -10,13 +10,14 @@
 //   * H is row-major [npad][ldh], npad = roundup(n,32), ldh = npad + 32.  The pad block is the
 //     identity (never pivoted into), and column `npad` carries the right-hand side, so the
 //     forward substitution L y = P b happens inside the factorisation and only U x = y remains.
-//   * right-looking outer blocks of NBO columns; each block column is factored by a host-driven
-//     recursion (halving down to 32-wide panels) so that every flop outside the 32-wide base
-//     panels is a call of the MFMA zgemm; row swaps are applied inside the block window by the
-//     recursion and, to the right of it, once per outer block (the L part to the left is never
-//     needed again because y is carried in the augmented column).
-//   * base panel: one workgroup per matrix, rows owned by threads, 4-column sub-blocks kept in
-//     registers; pivot rule = LAPACK izamax (max |re|+|im|, first index wins).
+//   * right-looking outer blocks of NBO (512) columns; each block column is factored by a host-driven
+//     recursion (halving down to 16-wide panels) so that every flop outside the base panels is a
+//     call of the MFMA zgemm; row swaps are applied inside the block window by the recursion and,
+//     to the right of it, once per outer block (the L part to the left is never needed again
+//     because y is carried in the augmented column).
+//   * base panel (16 columns): one workgroup per matrix, rows owned by threads, 4- or 2-column
+//     sub-blocks kept in registers and brought up to date left-looking while they are loaded;
+//     pivot rule = LAPACK izamax (max |re|+|im|, first index wins).
 #include "common.h"
 #include "luws.h"
 #include <cstdio>
@@ -117,9 +118,9 @@ load_h_kernel(const c128* __restrict__ Ain /*[G][n][n]*/, const c128* __restrict
 }
 
 // ---------------------------------------------------------------------------------------
-// Base panel: LU with partial pivoting of the m x 32 block at (j0, j0), m = npad - j0.
-// One workgroup (512 threads) per matrix; thread t owns rows t, t+512, ... (RPT of them).
-// Right-looking over 4-column sub-blocks held in registers.
+// Base panel, right-looking predecessor (MAUS_PANEL_LL=0; kept for A/B measurements): LU with partial
+// pivoting of the m x NBP block at (j0, j0), m = npad - j0.  One workgroup (512 threads) per matrix; thread t
+// owns rows t, t+512, ... (RPT of them).  Right-looking over 4-column sub-blocks held in registers.
 // ---------------------------------------------------------------------------------------
 template <int RPT>
 __global__ void __launch_bounds__(PT)
