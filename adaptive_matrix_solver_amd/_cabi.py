@@ -19,7 +19,7 @@ SYMBOLS = [
     "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get",
     "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_relax_normalise", "maus_residual",
     "maus_svd_power_step", "maus_set_eigvecs", "maus_herm_match", "maus_gmres", "maus_jacobi_check",
-    "maus_zgemm_host", "maus_zgemm_bench", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
+    "maus_gram", "maus_zgemm_host", "maus_zgemm_bench", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
     "maus_profile_enable", "maus_profile_read", "maus_sync", "maus_mt19937_jump",
 ]
 
@@ -77,6 +77,7 @@ def load_library():
         "maus_herm_match": ([vp, vp, C.c_int, vp, vp], C.c_int),
         "maus_gmres": ([vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_int, C.c_int, vp, vp, vp], C.c_int),
         "maus_jacobi_check": ([vp, C.c_int, vp, vp, vp], C.c_int),
+        "maus_gram": ([vp, C.c_int, vp, C.c_int, C.c_int, vp], C.c_int),
         "maus_zgemm_host": ([vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int], C.c_int),
         "maus_lu_solve_host": ([vp, C.c_int, C.c_int, vp, vp, vp, vp, vp], C.c_int),
         "maus_zgemm_bench": ([vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)], C.c_int),
@@ -271,6 +272,14 @@ class Context:
         nrm = np.empty(s.shape[0], dtype=np.float64)
         self._ck(self.lib.maus_herm_match(self.h, _ptr(s), s.shape[0], _ptr(idx), _ptr(nrm)), "maus_herm_match")
         return idx, nrm
+
+    def gram(self, which, slots, length):
+        """G[i, j] = np.vdot(x_i, x_j) for the rows `slots` of population array `which` (first `length` entries)."""
+        s = self._slots(slots)
+        k = s.shape[0]
+        out = np.empty((k, k), dtype=np.complex128)
+        self._ck(self.lib.maus_gram(self.h, int(which), _ptr(s), k, int(length), _ptr(out)), "maus_gram")
+        return out
 
     def gmres(self, slots, shift, psi, rhs_mode, use_jacobi, rtol=1e-8, restart=20, maxiter=50):
         s = self._slots(slots)

@@ -603,6 +603,34 @@ int maus_herm_match(maus_ctx* c, const int* slots, int count, int32_t* idx_out, 
     return 0;
 }
 
+// Gram block of candidate vectors (SURVEY f-2): G[i][j] = vdot(x_i, x_j) = sum_k conj(x_i[k]) x_j[k] over the rows
+// `slots` of population array `which`.  The rows are gathered into scratch once; the product is one zgemm in
+// dot-product layout with a conjugated left operand -- the same kernel as the Hermitian similarity row.
+__global__ void gather_rows_kernel(const c128* __restrict__ X, long ldx, const int* __restrict__ slots, int len,
+                                   c128* __restrict__ out) {
+    const c128* src = X + (long)slots[blockIdx.x] * ldx;
+    c128* dst = out + (long)blockIdx.x * len;
+    for (int k = threadIdx.x; k < len; k += blockDim.x) dst[k] = src[k];
+}
+
+int maus_gram(maus_ctx* c, int which, const int* slots, int count, int len, double* out_c128) {
+    c128* X = (which == MAUS_POP_X) ? c->X : (which == MAUS_POP_U) ? c->U : (which == MAUS_POP_W) ? c->W : nullptr;
+    if (!X) FAIL(c, "maus_gram: population array missing");
+    if (len <= 0 || len > c->ldp) FAIL(c, "maus_gram: bad vector length");
+    if (count == 0) return 0;
+    if (upload_slots(c, slots, count)) return -1;
+    const size_t rows = (size_t)count * len, g = (size_t)count * count;
+    if (ensure_scratch(c, sizeof(c128) * (rows + g))) return -1;
+    c128* R = (c128*)c->scratch; c128* G = R + rows;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(count), dim3(256), 0, c->st, X, c->ldp, c->d_slots, len, R);
+    { ProfScope ps(c, KC_GEMM, 8.0 * count * count * len, 16.0 * (2.0 * rows + g));
+      maus_zgemm_launch_idx(c->st, count, count, len, R, len, 0, R, len, 0, G, count, 0, 1.0, 0, 1, 1, true, false, nullptr, nullptr); }
+    HIPCHK(c, hipMemcpyAsync(out_c128, G, sizeof(c128) * g, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 int maus_gmres(maus_ctx* c, const int* slots, int count, const double* shift, const double* psi, int rhs_mode,
                const int32_t* use_jacobi, double rtol, int restart, int maxiter, int32_t* info_out, int32_t* inner_out, int32_t* status) {
     return maus_gmres_run(c, slots, count, shift, psi, rhs_mode, use_jacobi, rtol, restart, maxiter, info_out, inner_out, status);

@@ -277,6 +277,11 @@ class DeviceEngine:
         f = self._exchange(cands, loc)
         return f[:, 0].astype(np.int32), f[:, 1]
 
+    def d_gram(self, cands, which, length):
+        """abs-free Gram block G[i, j] = vdot(x_i, x_j) of the candidates' device rows (SURVEY f-2).  Every rank
+        holds every row after _sync_rows, so the block is computed redundantly (and identically) on each rank."""
+        return self.ctx.gram(which, [c._slot for c in cands], length)
+
     def _sync_rows(self, cands) -> None:
         """After a sharded step: every rank receives the rows its peers updated."""
         if self.comm is None or not cands:

@@ -336,7 +336,7 @@ class SolutionCandidate:
 class MAUS_Solver:
     def __init__(self, problem_matrix, problem_type, b_vector=None, initial_num_candidates=None,
                  global_convergence_tol=1e-8, *, device=0, pert_mode="auto", gmres_compat="rtol",
-                 record_history=None, comm=None, quiet=False, engine=None):
+                 record_history=None, comm=None, quiet=False, engine=None, gram_min=8):
         if _is_sparse(problem_matrix):
             raise NotImplementedError("sparse problems are outside the MI355X hot path (dense only)")
         self.M = problem_matrix.astype(np.complex128)                                   # AMS:343
@@ -369,6 +369,10 @@ class MAUS_Solver:
                                                                      gmres_compat=gmres_compat, comm=comm)
         self.engine.bind_matrix(self.M)
         self._record_history = record_history
+        # distinctness / redundancy tests (AMS:432-451, 509-520): with at least `gram_min` converged candidates the
+        # pairwise np.vdot calls are replaced by one device Gram block and vectorised comparisons (same greedy order,
+        # thresholds and arithmetic; SURVEY f-2)
+        self.gram_min = gram_min
         self._quiet = quiet
         initial_num_candidates = initial_num_candidates if initial_num_candidates is not None else (self.N_diag * 3)
         if self.problem_type == ProblemType.SVD:
@@ -450,8 +454,29 @@ class MAUS_Solver:
             sp_["current_convergence_threshold"] = max(1e-5, sp_["convergence_tolerance"])
 
     # ---- AMS:424-475 ------------------------------------------------------------------------------
+    def _converged_gram(self):
+        """(position map, |Gram| blocks) over the CONVERGED candidates in list order, or (None, None) when the set is
+        small / the problem type has no vector test.  EIG: {'v'}; SVD: {'u', 'v'}."""
+        from ._cabi import POP_U, POP_X
+        C = SolutionCandidate.State
+        if self.problem_type not in (ProblemType.EIGENVALUE, ProblemType.SVD):
+            return None, None
+        conv = [c for c in self.candidates if c.state == C.CONVERGED]
+        if len(conv) < max(2, self.gram_min):
+            return None, None
+        for c in conv:
+            c._push()                                    # host-side edits (if any) reach the device rows first
+        eng = self.engine
+        if self.problem_type == ProblemType.EIGENVALUE:
+            blocks = {"v": np.abs(eng.d_gram(conv, POP_X, self.N_diag))}
+        else:
+            blocks = {"u": np.abs(eng.d_gram(conv, POP_U, self.N_rows)), "v": np.abs(eng.d_gram(conv, POP_X, self.N_cols))}
+        return {id(c): i for i, c in enumerate(conv)}, blocks
+
     def _update_global_diagnostics(self, iteration):
         C = SolutionCandidate.State
+        gpos, gram = self._converged_gram()
+        acc_pos, acc_key = [], []                          # Gram positions / lambda (sigma) of the accepted solutions
         total_active_candidates = len(self.candidates)
         sum_residuals = 0.0
         sum_stuck_counters = 0
@@ -467,7 +492,13 @@ class MAUS_Solver:
                 is_distinct = True
                 if current_tuple is None or any(p is None for p in current_tuple):
                     continue
-                if self.problem_type == ProblemType.EIGENVALUE:
+                if self.problem_type == ProblemType.EIGENVALUE and gram is not None:
+                    if acc_pos:
+                        s_lam = np.asarray(acc_key)
+                        close = np.abs(current_tuple[0] - s_lam) < (GLOBAL_LAMBDA_SIMILARITY_TOL + np.abs(s_lam) * 1e-6)
+                        if close.any() and (close & (gram["v"][gpos[id(c)], acc_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)).any():
+                            is_distinct = False
+                elif self.problem_type == ProblemType.EIGENVALUE:
                     for s_item in self.converged_solutions:
                         s_lam, s_vec = s_item[0], s_item[1]
                         effective_tol = GLOBAL_LAMBDA_SIMILARITY_TOL + np.abs(s_lam) * 1e-6
@@ -485,7 +516,15 @@ class MAUS_Solver:
                                  if cand.sigma_k is not None and cand.sigma_k.real > 0), default=1.0)
                     if current_tuple[0].real / max_s < GLOBAL_SIGMA_SIMILARITY_TOL_REL:
                         is_distinct = False
-                    if is_distinct:
+                    if is_distinct and gram is not None:
+                        if acc_pos:
+                            s_sig = np.asarray(acc_key)
+                            close = np.abs(current_tuple[0] - s_sig) < np.maximum(GLOBAL_SIGMA_SIMILARITY_TOL_ABS, s_sig * GLOBAL_SIGMA_SIMILARITY_TOL_REL)
+                            i = gpos[id(c)]
+                            if close.any() and (close & (gram["u"][i, acc_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)
+                                                & (gram["v"][i, acc_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)).any():
+                                is_distinct = False
+                    elif is_distinct:
                         for s_item in self.converged_solutions:
                             s_sigma, s_u, s_v = s_item
                             if (np.abs(current_tuple[0] - s_sigma) < max(GLOBAL_SIGMA_SIMILARITY_TOL_ABS, s_sigma * GLOBAL_SIGMA_SIMILARITY_TOL_REL)
@@ -497,6 +536,9 @@ class MAUS_Solver:
                 if is_distinct:
                     self.converged_solutions.append(current_tuple)
                     self.num_distinct_converged_solutions += 1
+                    if gram is not None:
+                        acc_pos.append(gpos[id(c)])
+                        acc_key.append(current_tuple[0])
             if c.state not in (C.CONVERGED, C.RETIRED):
                 sum_residuals += c.residual_k if np.isfinite(c.residual_k) else (thr * 100)
                 sum_stuck_counters += c.stuck_counter
@@ -558,9 +600,24 @@ class MAUS_Solver:
         sorted_candidates = sorted(self.candidates,
                                    key=lambda x: (-x.w_k, x.residual_k if np.isfinite(x.residual_k) else float("inf")))
         tol = self.strat_params["convergence_tolerance"]
+        gpos, gram = self._converged_gram()
+        sur_pos, sur_key = [], []                          # Gram positions / lambda (sigma) of the converged survivors
         for c in sorted_candidates:
             redundant = False
-            if c.state == C.CONVERGED:
+            if c.state == C.CONVERGED and gram is not None:
+                tc = c.get_current_solution_params()
+                if sur_pos and not (tc is None or any(p is None for p in tc)):
+                    i = gpos[id(c)]
+                    key = np.asarray(sur_key)
+                    if self.problem_type == ProblemType.EIGENVALUE:
+                        close = np.abs(tc[0] - key) < (GLOBAL_LAMBDA_SIMILARITY_TOL + np.abs(key) * 1e-6)
+                        redundant = bool(close.any() and (close & (gram["v"][i, sur_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)).any())
+                    else:
+                        live = ~(key.real < GLOBAL_SIGMA_SIMILARITY_TOL_ABS / 100)
+                        close = np.abs(tc[0] - key) < np.maximum(GLOBAL_SIGMA_SIMILARITY_TOL_ABS, key * GLOBAL_SIGMA_SIMILARITY_TOL_REL)
+                        redundant = bool((live & close & (gram["u"][i, sur_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)
+                                          & (gram["v"][i, sur_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)).any())
+            elif c.state == C.CONVERGED:
                 for s_c in survivors:
                     if s_c.state != C.CONVERGED:
                         continue
@@ -593,6 +650,11 @@ class MAUS_Solver:
                 c.state = C.RETIRED
             else:
                 survivors.append(c)
+                if gram is not None and c.state == C.CONVERGED:
+                    ts = c.get_current_solution_params()
+                    if not (ts is None or any(p is None for p in ts)):
+                        sur_pos.append(gpos[id(c)])
+                        sur_key.append(ts[0])
         self.candidates = survivors
         target = self.N_diag
         if self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:

@@ -131,6 +131,12 @@ int maus_svd_power_step(maus_ctx* ctx, const int* slots, int count, double* norm
 int maus_set_eigvecs(maus_ctx* ctx, const double* v_c128, int n);
 int maus_herm_match(maus_ctx* ctx, const int* slots, int count, int32_t* idx_out, double* norm_out);
 
+/* Gram block of candidate vectors for the distinctness / redundancy tests      AMS:432-437, 443-451, 509-520:
+ * out[i*count + j] = vdot(x_i, x_j) = sum_k conj(x_i[k]) x_j[k] over the first `len` entries of rows `slots`
+ * of population array `which` (MAUS_POP_X / MAUS_POP_U).  Replaces the reference's pairwise np.vdot calls
+ * between converged candidates; the host keeps the reference's greedy order and thresholds. */
+int maus_gram(maus_ctx* ctx, int which, const int* slots, int count, int len, double* out_c128);
+
 /* Batched restarted GMRES with optional Jacobi preconditioner       AMS:60-90 ->
  * scipy/sparse/linalg/_isolve/iterative.py:692-841 (restart 20, MGS, Givens, ptol).
  *   H_k = A - shift_k I + psi_k I (MAUS_PERT_NONE only); x0 = rhs; W[slot] <- x

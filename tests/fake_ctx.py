@@ -157,6 +157,10 @@ class FakeContext:
             self.pop[0][s, : self.cols] = w / (s2 if s2 > 1e-10 else 1.0)
         return out
 
+    def gram(self, which, slots, length):
+        R = self.pop[which][list(slots), :length]
+        return R.conj() @ R.T
+
     def herm_match(self, slots):
         n = self.rows
         idx = np.empty(len(slots), dtype=np.int32)

@@ -92,3 +92,19 @@ def test_lu_tie_breaking_first_index(ctx):
     lu, piv = sla.lu_factor(A)
     assert status[0] == 0 and np.array_equal(ipiv[0], piv)
     assert np.allclose(x[0], sla.solve(A, b), rtol=1e-13)
+
+
+@pytest.mark.parametrize("count,n", [(1, 7), (5, 33), (40, 300), (130, 1024)])
+def test_gram_block_matches_numpy(ctx, count, n):
+    """maus_gram: G[i, j] = np.vdot(x_i, x_j) over scattered population slots (SURVEY f-2)."""
+    rng = np.random.default_rng(count * 1000 + n)
+    A = crand(rng, n, n)
+    ctx.set_matrix(A)
+    ctx.pop_reserve(2 * count + 3)
+    slots = list(rng.permutation(2 * count + 3)[:count])
+    X = crand(rng, count, n)
+    ctx.pop_put(0, slots, X)
+    G = ctx.gram(0, slots, n)
+    ref = X.conj() @ X.T
+    assert np.abs(G - ref).max() <= 4e-16 * np.sqrt(n) * (np.abs(X) @ np.abs(X).T).max()
+    assert np.allclose(np.diag(G).imag, 0.0, atol=1e-13 * n)

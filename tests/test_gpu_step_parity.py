@@ -205,6 +205,20 @@ def test_linear_fragile_real_gmres(pert_mode):
     compare(ref, got, anorm, "lin32f-rtol-" + pert_mode)
 
 
+@pytest.mark.parametrize("name,iters", [("lap8", 60), ("herm64", 3), ("svd5x4", 30)])
+def test_gram_path_makes_the_same_decisions(name, iters):
+    """Distinctness / redundancy tests through the device Gram block (gram_min=2) against the reference's pairwise
+    np.vdot order (gram_min huge): identical bookkeeping, survivors and RNG streams, iteration by iteration."""
+    a = product_run(name, iters, pert_mode="uniform", gmres_compat="scipy-legacy", gram_min=2)
+    b = product_run(name, iters, pert_mode="uniform", gmres_compat="scipy-legacy", gram_min=10 ** 9)
+    for it, (x, y) in enumerate(zip(a, b)):
+        tag = f"{name} iter {it}"
+        assert [(r["id"], r["state"], r["stuck"], r["retries"], r["resets"]) for r in x["rows"]] == \
+               [(r["id"], r["state"], r["stuck"], r["retries"], r["resets"]) for r in y["rows"]], tag
+        assert x["after"] == y["after"] and x["rng"] == y["rng"] and x["n_distinct"] == y["n_distinct"], tag
+        assert x["energy"] == y["energy"], tag
+
+
 def test_nan_ladder():
     """NaN-poisoned matrix: every step is a total failure (26 solve attempts), STUCK x7 then RETIRED."""
     import random
