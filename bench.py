@@ -38,11 +38,25 @@ def cpu_baseline(A, n, budget_s=25.0):
     tests/) timed on this host: whole candidate steps, first attempt succeeds, including the two
     rand(N,N) draws, the N x N temporaries and zgecon that the reference performs."""
     from oracle import maus_oracle as orc
+    blas = "unknown"
     try:
         from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        pools = threadpool_info()
+        threads = max([p.get("num_threads", 1) for p in pools] or [1])
+        blas = "; ".join(sorted({f"{p.get('internal_api', '?')} {p.get('version', '?')} ({p.get('architecture', '?')})"
+                                 for p in pools if p.get("user_api") == "blas"})) or "unknown"
     except Exception:
         threads = os.cpu_count() or 1
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    import scipy
     st_np, st_py = np.random.get_state(), random.getstate()
     orc.seed_all(4242)
     strat = {"overall_psi_aggression_factor": 1.0, "max_psi_retries": 25, "current_convergence_threshold": 1e-8,
@@ -63,6 +77,7 @@ def cpu_baseline(A, n, budget_s=25.0):
     el = time.perf_counter() - t0
     np.random.set_state(st_np); random.setstate(st_py)
     return {"value": steps / el, "unit": "candidate-steps/s", "cores": int(threads), "kind": "port",
+            "cpu_model": cpu_model, "blas": blas, "numpy": np.__version__, "scipy": scipy.__version__,
             "sample": f"{steps} whole candidate steps (2 candidates x {steps // 2} iterations) of the NumPy/SciPy oracle at n={n}, "
                       f"{el:.1f} s, BLAS threads={threads}, host cpus={os.cpu_count()}"}
 
