@@ -34,7 +34,8 @@ namespace {
 #ifndef MAUS_NBP
 #define MAUS_NBP 16
 #endif
-constexpr int NBP = MAUS_NBP;   // base panel width (16: measured best; 32 moves ~4x more in-kernel traffic per panel)
+constexpr int NBP = MAUS_NBP;   // base panel width.  16 vs 32 with the left-looking panel: 294-297 vs 296 candidate-steps/s
+                                // (the wider panel costs what the K=16 update level saves); with the right-looking panel 16 won clearly
 constexpr int AUG = 32;         // augmented (rhs) column block, also the padding granule of n
 constexpr int BSB = 32;         // back-substitution block
 constexpr int PW = 4;       // register sub-block width inside the panel
