@@ -198,6 +198,20 @@ def main():
                                     "hbm_over_algorithmic": ratio, "source": "profiles/r01_zgemm_pmc_traffic.json"}
         except Exception:
             traffic = None
+        # HBM-bound kernels: bytes per sweep from the committed PMC passes / their time in the isolated pass
+        hbm_kernels = None
+        try:
+            if iso is not None and n == 4096 and P == 256:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_per_kernel.json")) as f:
+                    classes = json.load(f)["classes"]
+                hbm_kernels = {}
+                for name in ("laswp", "trsm", "build_h", "lu_panel", "backsolve"):
+                    if name in classes and iso.get(name, {}).get("ms", 0) > 0:
+                        gbs = classes[name]["hbm_bytes"] / (iso[name]["ms"] * 1e-3) / 1e9
+                        hbm_kernels[name] = {"ms_per_sweep": round(iso[name]["ms"], 3), "hbm_bytes_per_sweep": classes[name]["hbm_bytes"],
+                                             "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 3)}
+        except Exception:
+            hbm_kernels = None
         out = {
             "metric": "candidate-steps/sec, n=4096 dense eig pop=256, 1/2/4/8 GPUs vs CPU ref",
             "value": steps_done / elapsed, "unit": "candidate-steps/s",
@@ -235,6 +249,7 @@ def main():
                          "mfma_pipe_executed_tflops": achieved * 0.75 if os.environ.get("MAUS_GEMM_3M", "1") != "0" else achieved,
                          "mfma_pipe_frac": (achieved * 0.75 if os.environ.get("MAUS_GEMM_3M", "1") != "0" else achieved) / FP64_MFMA_PEAK_TFLOPS},
             ("kernel_ms" if args.kernel_events == "all" else "kernel_ms_estimated_from_sampled_launches"): {k: round(v["ms"], 3) for k, v in prof.items()},
+            "hbm_bound_kernels": hbm_kernels,
             "step_tflops": (8.0 / 3.0 * n ** 3 + 24.0 * n * n) * steps_done / elapsed / 1e12,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -56,6 +56,16 @@ for d in dirs:
             a[0] += 1
             a[1] += float(r["Counter_Value"])
 
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+per_class = {}
+for k, cs in acc.items():
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        per_class[k] = {"launches": cs["FETCH_SIZE"][0], "fetch_bytes": cs["FETCH_SIZE"][1] * 1024.0 * 2.0,
+                        "write_bytes": cs["WRITE_SIZE"][1] * 1024.0}
+        per_class[k]["hbm_bytes"] = per_class[k]["fetch_bytes"] + per_class[k]["write_bytes"]
+json.dump({"unit": "bytes per bench step (one 271-solve sweep, MAUS_LU_STREAMS=1)", "classes": per_class,
+           "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950), WRITE_SIZE as reported; separate --pmc passes"},
+          open(os.path.join(root, "gpurun_out", "pmc_traffic_per_kernel.json"), "w"), indent=1)
 for k, cs in acc.items():
     parts = []
     for c, (n, v) in sorted(cs.items()):
