@@ -336,7 +336,7 @@ class SolutionCandidate:
 class MAUS_Solver:
     def __init__(self, problem_matrix, problem_type, b_vector=None, initial_num_candidates=None,
                  global_convergence_tol=1e-8, *, device=0, pert_mode="auto", gmres_compat="rtol",
-                 record_history=None, comm=None, quiet=False, engine=None, gram_min=8):
+                 record_history=None, comm=None, quiet=False, engine=None, gram_min=8, cond_exact_max=1024):
         if _is_sparse(problem_matrix):
             raise NotImplementedError("sparse problems are outside the MI355X hot path (dense only)")
         self.M = problem_matrix.astype(np.complex128)                                   # AMS:343
@@ -344,6 +344,11 @@ class MAUS_Solver:
         self.N_diag = self.N_rows
         self.problem_type = problem_type
         self.b = b_vector.astype(np.complex128) if b_vector is not None else None
+        # start-up diagnostics (AMS:374-404): above `cond_exact_max` the condition number comes from the GPU estimator
+        # (engine.estimate_condition_number) unless it lands near one of the thresholds it feeds; `engine` (the test
+        # seam) keeps the reference's exact computation
+        self._cond_device = device if (engine is None and cond_exact_max is not None) else None
+        self._cond_exact_max = cond_exact_max
         self.diag_info = self._diagnose_matrix_initial(self.M)
         self.is_sparse_problem_init = self.diag_info["is_sparse_init"]
         self.cond_number = self.diag_info["condition_number"]
@@ -416,7 +421,16 @@ class MAUS_Solver:
         if (not diag_info["is_sparse_init"] and isinstance(matrix, np.ndarray) and matrix.ndim == 2
                 and matrix.shape[0] == matrix.shape[1] and matrix.size > 0):
             try:
-                cond_num_val = np.linalg.cond(matrix)
+                cond_num_val = None
+                if getattr(self, "_cond_device", None) is not None and matrix.shape[0] > self._cond_exact_max:
+                    from .engine import estimate_condition_number
+                    kappa, trusted = estimate_condition_number(matrix, device=self._cond_device)
+                    diag_info["condition_number_estimate"] = kappa
+                    if trusted:
+                        cond_num_val = kappa
+                diag_info["condition_number_is_estimate"] = cond_num_val is not None
+                if cond_num_val is None:
+                    cond_num_val = np.linalg.cond(matrix)
                 if np.isinf(cond_num_val) or cond_num_val > 1e15:
                     is_singular_val = True
             except np.linalg.LinAlgError:
