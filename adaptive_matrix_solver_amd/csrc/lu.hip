@@ -503,6 +503,8 @@ lu_panel_ll_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
 
 // ---------------------------------------------------------------------------------------
 // Row interchanges ipiv[k1..k2) applied to columns [c_lo, c_hi); one thread per column.
+// (Measured and rejected: applying the net permutation of the block instead of the swap sequence, and issuing the
+// loads of 8 pairwise-independent swaps before their stores -- 56 and 70 ms per sweep against 49 for this loop.)
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 laswp_kernel(c128* __restrict__ Hg, long ld, long strideH, const int* __restrict__ ipiv_g, int npad,
