@@ -714,9 +714,48 @@ class MAUS_Solver:
         return n
 
     # ---- AMS:551-608 ------------------------------------------------------------------------------
-    def evolve(self, max_iterations=100):
+    def _reference_solution(self):
+        """The reference's reporting prologue (AMS:554-570): a SciPy answer to compare the final report with.
+        O(n^3) on the host; evolve() runs it by default only up to n = 1024."""
+        import scipy.linalg as sla
+        try:
+            if self.M.size == 0:
+                raise ValueError("Matrix is empty.")
+            if self.problem_type == ProblemType.EIGENVALUE:
+                if self.N_rows != self.N_cols:
+                    raise ValueError("Non-square matrix for Eigenvalue.")
+                vals = sla.eigvals(self.M)
+                vals.sort()
+                return vals
+            if self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
+                if self.b is None:
+                    raise ValueError("b_vector is None.")
+                if self.N_rows != self.b.shape[0]:
+                    raise ValueError("A,b shape mismatch.")
+                return sla.solve(self.M, self.b, assume_a="general")
+            return sorted(sla.svd(self.M, compute_uv=False).tolist(), reverse=True)
+        except (np.linalg.LinAlgError, ValueError) as e:
+            print(f"NumPy reference calculation failed: {e}.")
+            return None
+
+    def _report_residual(self, t):
+        """Residual of one reported solution tuple, recomputed from the problem matrix (AMS:594-596)."""
+        M = self.M
+        if self.problem_type == ProblemType.EIGENVALUE:
+            return np.linalg.norm(M @ t[1] - t[0] * t[1])
+        if self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
+            return np.linalg.norm(M @ t[0] - self.b)
+        return np.linalg.norm(M @ t[2] - t[0] * t[1]) + np.linalg.norm(M.conj().T @ t[1] - t[0] * t[2])
+
+    def evolve(self, max_iterations=100, *, reference_check=None):
+        """AMS:551-608.  `reference_check`: run the reference's SciPy prologue and the closing comparison (None = only
+        for n <= 1024, where the host O(n^3) solve is cheap; True / False force it)."""
         print(f"--- Starting MAUS Evolution for {max_iterations} iterations ({self.problem_type.name}) ---")
-        self.true_solution = None       # the reference's SciPy "true solution" prologue is reporting only
+        self.true_solution = None
+        if reference_check is None:
+            reference_check = max(self.N_rows, self.N_cols) <= 1024
+        if reference_check:
+            self.true_solution = self._reference_solution()
         for i in range(max_iterations):
             self.loop_body(i + 1)
             target_sols_disp = self.N_diag
@@ -737,15 +776,37 @@ class MAUS_Solver:
                 print(f"WARNING: Max iterations. Found {self.num_distinct_converged_solutions}/{target_sols_final}.")
         print("--- MAUS Evolution COMPLETE ---")
         print("Final Report:")
-        sols = self.converged_solutions
+        sols = list(self.converged_solutions)
         if self.problem_type == ProblemType.EIGENVALUE:
-            sols = sorted(sols, key=lambda x: (x[0].real, x[0].imag))
+            sols.sort(key=lambda x: (x[0].real, x[0].imag) if x[0] is not None else (float("inf"), float("inf")))
         elif self.problem_type == ProblemType.SVD:
-            sols = sorted(sols, key=lambda x: -x[0].real)
+            sols.sort(key=lambda x: -x[0].real if x[0] is not None else float("-inf"))
         for k, t in enumerate(sols):
+            if t is None or any(p is None for p in t):
+                print(f"  Solution {k+1}: Invalid")
+                continue
+            res = self._report_residual(t)
             if self.problem_type == ProblemType.EIGENVALUE:
-                print(f"  Eig {k+1}: λ={t[0]:.6e}")
+                print(f"  Eig {k+1}: λ={t[0]:.6e}, Res={res:.2e}")
             elif self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
-                print(f"  LinSolve {k+1}: X_norm1={np.linalg.norm(t[0], 1):.6e}")
+                print(f"  LinSolve {k+1}: X_norm1={np.linalg.norm(t[0], 1):.6e}, Res={res:.2e}")
             else:
-                print(f"  SVD {k+1}: σ={t[0]:.6e}")
+                print(f"  SVD {k+1}: σ={t[0]:.6e}, Res={res:.2e}")
+        if self.true_solution is not None and self.num_distinct_converged_solutions > 0 and sols:
+            print("--- Comparison to NumPy ---")
+            if self.problem_type == ProblemType.EIGENVALUE:
+                found = np.array(sorted([t[0] for t in sols if t[0] is not None], key=lambda z: (z.real, z.imag)))
+                ref = self.true_solution[:len(found)]
+                if found.size > 0 and ref.size > 0:
+                    print(f"Mean abs error (eigs): {np.sum(np.abs(found - ref)) / len(found):.2e}")
+            elif self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
+                if sols[0][0] is not None:
+                    err, nref = np.linalg.norm(sols[0][0] - self.true_solution), np.linalg.norm(self.true_solution)
+                    print(f"Rel error (X): {err / nref if nref > 1e-10 else err:.2e}")
+            else:
+                found = np.array(sorted([t[0].real for t in sols if t[0] is not None], reverse=True))
+                ref = np.array(self.true_solution[:len(found)])
+                if found.size > 0 and ref.size > 0:
+                    nref = np.linalg.norm(ref)
+                    err = np.linalg.norm(found - ref)
+                    print(f"Rel error (sigmas): {err / nref if nref > 1e-10 else err:.2e}")
