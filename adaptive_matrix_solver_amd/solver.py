@@ -48,6 +48,20 @@ GLOBAL_CONVERGENCE_RESIDUAL_TOL = 1e-8
 GLOBAL_MAX_STUCK_FOR_PRUNING = 4
 
 
+def _allclose_to_transpose(M, conj: bool, rows_per_block: int = 256) -> bool:
+    """np.allclose(M, M.conj().T) / np.allclose(M, M.T) evaluated block row by block row.  allclose is a conjunction of
+    one elementwise predicate, so the answer is the same; a matrix that is not (conjugate-)symmetric is rejected at
+    its first block instead of after a strided pass over all of it (3 s per check at n=4096)."""
+    n = M.shape[0]
+    for i in range(0, n, rows_per_block):
+        other = M[:, i:i + rows_per_block].T
+        if conj:
+            other = other.conj()
+        if not np.allclose(M[i:i + rows_per_block, :], other):
+            return False
+    return True
+
+
 def _is_sparse(M) -> bool:
     try:
         import scipy.sparse as sp
@@ -410,9 +424,9 @@ class MAUS_Solver:
             diag_info["is_sparse_init"] = (np.count_nonzero(matrix) / matrix.size) < 0.25 if matrix.size > 0 else False
             try:
                 if matrix.ndim == 2 and matrix.shape[0] == matrix.shape[1]:
-                    if np.allclose(matrix, matrix.conj().T):
+                    if _allclose_to_transpose(matrix, conj=True):              # np.allclose(M, M.conj().T), AMS:381
                         diag_info["is_hermitian"] = True
-                    if np.allclose(matrix, matrix.T):
+                    if _allclose_to_transpose(matrix, conj=False):             # np.allclose(M, M.T), AMS:383
                         diag_info["is_complex_symmetric"] = True
             except Exception:
                 pass
