@@ -65,7 +65,11 @@ zgemm_kernel(int M, int N, int K,
     // B block of the current column block (WC x BN x K) stays resident in the XCD's 4 MB L2 while the
     // A row panels stream past it once.  Row-major order re-streamed all of B for every tile row
     // (PMC: FETCH_SIZE 3.5x the algorithmic reads; profiles/r01_pmc_traffic_before_l2_blocking.txt).
-    constexpr int WC = 8;
+    // (4 / 8 / 16 / 32 tile columns per block: 79.3-79.8 TFLOP/s at K = 512 in every case, tools/gemm_k512_check.py)
+#ifndef MAUS_WC
+#define MAUS_WC 8
+#endif
+    constexpr int WC = MAUS_WC;
     const int tiles_m = nwg / tiles_n;
     const int full = tiles_m * WC;
     int cb = bid / full, rem = bid - cb * full, wl = WC;
