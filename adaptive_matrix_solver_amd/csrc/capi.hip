@@ -107,9 +107,10 @@ int maus_ctx_destroy(maus_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
     void* ptrs[] = {c->A, c->b, c->V, c->X, c->U, c->W, c->Y, c->d_slots, c->d_i1, c->d_i2, c->d_c1, c->d_c2, c->d_r1, c->d_r2,
-                    c->H, c->ipiv, c->info, c->flags, c->Upert, c->scratch, c->mt_states, c->mt_int, c->mt_base};
+                    c->H, c->ipiv, c->info, c->flags, c->Upert, c->scratch};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : c->mt_taps) if (kv.second.first) (void)hipFree(kv.second.first);
+    for (auto& b : c->mt_bufs) { if (b.states) (void)hipFree(b.states); if (b.ints) (void)hipFree(b.ints); if (b.base) (void)hipFree(b.base); }
     for (auto& r : c->pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     for (auto st : c->lu_st) (void)hipStreamDestroy(st);
@@ -327,7 +328,9 @@ static void finish_status(int G, const int* info, const int* flags, int32_t* sta
 
 // MAUS_PERT_MT19937: generator start states for candidates [first, first+g) of the run by binary lifting (over the
 // draw index m, then over the sub-stream index b), then the H build that regenerates the draws (mtdev.hip).
-static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* d, int first, int g, int rhs_mode, int lo) {
+static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* d, int first, int g, int rhs_mode, int lo, int sbi) {
+    if ((int)c->mt_bufs.size() <= sbi) c->mt_bufs.resize(sbi + 1);
+    maus_ctx::MtBuf& mb = c->mt_bufs[sbi];
     const int n = w.n;
     const uint64_t two_n2 = 2ull * n * n;
     if (d->pos < 0 || d->pos > 624) FAIL(c, "maus_mt_desc: bad position");
@@ -340,13 +343,13 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
     { const char* e = getenv("MAUS_MT_SUBSTREAMS"); if (e) S = std::max(1, std::min(16, atoi(e))); }
     const uint64_t E = (nn + S - 1) / S;                          // elements per sub-stream
     const int ngen = 2 * g * S;
-    if (ngen > c->mt_cap) {
-        void** ps[] = {(void**)&c->mt_states, (void**)&c->mt_base};
+    if (ngen > mb.cap) {
+        void** ps[] = {(void**)&mb.states, (void**)&mb.base};
         for (auto p : ps) if (*p) { (void)hipFree(*p); *p = nullptr; }
         const int cap = std::max(ngen, 4096);
-        HIPCHK(c, hipMalloc((void**)&c->mt_states, sizeof(uint32_t) * 624 * (size_t)cap));
-        HIPCHK(c, hipMalloc((void**)&c->mt_base, sizeof(uint32_t) * 624));
-        c->mt_cap = cap;
+        HIPCHK(c, hipMalloc((void**)&mb.states, sizeof(uint32_t) * 624 * (size_t)cap));
+        HIPCHK(c, hipMalloc((void**)&mb.base, sizeof(uint32_t) * 624));
+        mb.cap = cap;
     }
     const uint64_t dblocks = two_n2 / 624;
     const uint64_t dj = dblocks >= 2 ? dblocks - 1 : 0;          // jump stride (blocks) per draw; >= 1 real regeneration follows
@@ -401,21 +404,21 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
     };
     if (plan(m, maxm, dj)) return -1;
     if (plan(bsel, maxb, dj2)) return -1;
-    if (hs.size() > c->mt_int_cap) {
-        if (c->mt_int) { (void)hipFree(c->mt_int); c->mt_int = nullptr; }
+    if (hs.size() > mb.int_cap) {
+        if (mb.ints) { (void)hipFree(mb.ints); mb.ints = nullptr; }
         const size_t cap = hs.size() * 2;
-        HIPCHK(c, hipMalloc((void**)&c->mt_int, sizeof(int) * cap));
-        c->mt_int_cap = cap;
+        HIPCHK(c, hipMalloc((void**)&mb.ints, sizeof(int) * cap));
+        mb.int_cap = cap;
     }
-    HIPCHK(c, hipMemcpyAsync(c->mt_base, d->key, sizeof(uint32_t) * 624, hipMemcpyHostToDevice, w.st));
-    HIPCHK(c, hipMemcpyAsync(c->mt_int, hs.data(), sizeof(int) * hs.size(), hipMemcpyHostToDevice, w.st));
+    HIPCHK(c, hipMemcpyAsync(mb.base, d->key, sizeof(uint32_t) * 624, hipMemcpyHostToDevice, w.st));
+    HIPCHK(c, hipMemcpyAsync(mb.ints, hs.data(), sizeof(int) * hs.size(), hipMemcpyHostToDevice, w.st));
     HIPCHK(c, hipStreamSynchronize(w.st));                       // staging (hs, d->key) is reusable from here on
-    maus_mt_copy_states(w.st, c->mt_states, c->mt_base, ngen);
-    for (const Level& L : levels) maus_mt_jump(w.st, c->mt_states, c->mt_int + L.off, L.count, L.taps, L.ntap16);
-    const int* d_extra = c->mt_int; const int* d_rpos = c->mt_int + ngen;
+    maus_mt_copy_states(w.st, mb.states, mb.base, ngen);
+    for (const Level& L : levels) maus_mt_jump(w.st, mb.states, mb.ints + L.off, L.count, L.taps, L.ntap16);
+    const int* d_extra = mb.ints; const int* d_rpos = mb.ints + ngen;
     prof_tick(c, KC_BUILD, 0, 0, 0);
     maus_build_h_mt(w.st, c->A, n, w.npad, w.ldh, w.strideH, w.H, g, S, (long)E, c->d_c1 + lo, c->d_r1 + lo, rhs_mode, c->X, c->ldp,
-                    c->d_slots + lo, c->b, c->mt_states, d_extra, d_rpos, w.flags);
+                    c->d_slots + lo, c->b, mb.states, d_extra, d_rpos, w.flags);
     prof_tick(c, KC_BUILD, 1, 0, 32.0 * w.npad * w.ldh * g);
     return 0;
 }
@@ -468,7 +471,7 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             w.H += (long)lo * w.strideH; w.ipiv += (long)lo * w.npad; w.info += lo; w.flags += lo; w.st = st;
             c->prof_st = st;
             if (pert_mode == MAUS_PERT_MT19937) {
-                if (mt_prepare_and_build(c, w, (const maus_mt_desc*)pert_data, off + lo, g, rhs_mode, lo)) return -1;
+                if (mt_prepare_and_build(c, w, (const maus_mt_desc*)pert_data, off + lo, g, rhs_mode, lo, sb)) return -1;
             } else
             maus_build_h(w, c->A, c->d_c1 + lo, c->d_r1 + lo, rhs_mode, c->X, c->ldp, c->d_slots + lo, c->b, pert_mode,
                          dU ? dU + 2 * (size_t)n * n * lo : nullptr);

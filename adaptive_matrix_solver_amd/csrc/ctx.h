@@ -61,7 +61,10 @@ struct maus_ctx {
     int *ipiv = nullptr, *info = nullptr, *flags = nullptr;
     double* Upert = nullptr; size_t Ubytes = 0;
     // device-side MT19937 regeneration (mtdev.hip)
-    uint32_t* mt_states = nullptr; int* mt_int = nullptr; uint32_t* mt_base = nullptr; int mt_cap = 0; size_t mt_int_cap = 0;
+    // one buffer set per sub-batch stream: the host prepares sub-batch s+1 while the jump / build kernels of sub-batch s
+    // still read theirs
+    struct MtBuf { uint32_t* states = nullptr; int* ints = nullptr; uint32_t* base = nullptr; int cap = 0; size_t int_cap = 0; };
+    std::vector<MtBuf> mt_bufs;
     std::map<uint64_t, std::pair<int*, int>> mt_taps;   // J -> (device tap list of x^J mod phi, #taps/16)
     std::vector<int> mt_host;                           // staging for the per-level selections
     // sub-batch streams: bandwidth-bound phases (panel, swaps, trsm) of one sub-batch overlap the

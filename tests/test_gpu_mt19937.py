@@ -96,3 +96,34 @@ def test_trajectory_with_device_draws(name, iters):
     ref, anorm = oracle_run(name, iters)
     got = product_run(name, iters, pert_mode="mt19937", gmres_compat="scipy-legacy")
     compare(ref, got, anorm, name + "-mt19937")
+
+
+def test_two_sub_batch_streams_keep_their_own_generator_state(ctx):
+    """>= 192 solves run as two sub-batches on two streams: each needs its own generator buffers (the host prepares
+    the second while the first still reads its states).  Same bits as the host-drawn path, with a psi large enough
+    for the perturbation to reach the leading digits."""
+    from adaptive_matrix_solver_amd._cabi import PERT_MT19937, PERT_UNIFORM
+    n, count = 96, 200
+    rng = np.random.default_rng(11)
+    A = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) / np.sqrt(n)
+    V = rng.standard_normal((count, n)) + 1j * rng.standard_normal((count, n))
+    ctx.set_matrix(A)
+    ctx.pop_reserve(count)
+    slots = list(range(count))
+    ctx.pop_put(0, slots, V)
+    lam = (rng.standard_normal(count) + 1j * rng.standard_normal(count)) * 0.2
+    psi = np.full(count, 0.05)
+    np.random.seed(77)
+    np.random.rand(5)
+    st = np.random.get_state()
+    U = np.empty((count, 2, n, n))
+    for k in range(count):
+        U[k, 0] = np.random.rand(n, n)
+        U[k, 1] = np.random.rand(n, n)
+    for rep in range(3):            # the hazard is a race: give it a few chances
+        s1 = ctx.shifted_lu_solve(slots, lam, psi, 0, PERT_UNIFORM, U)
+        W1 = ctx.pop_get(2, slots, n)
+        s2 = ctx.shifted_lu_solve(slots, lam, psi, 0, PERT_MT19937, (st, 4 * n * n, 0, np.arange(count, dtype=np.int32)))
+        W2 = ctx.pop_get(2, slots, n)
+        assert (s1 == 0).all() and (s2 == 0).all()
+        assert np.array_equal(W1, W2), f"rep {rep}: {np.argwhere(np.any(W1 != W2, axis=1)).ravel()[:8]}"
