@@ -99,7 +99,7 @@ def test_trajectory_with_device_draws(name, iters):
 
 
 def test_two_sub_batch_streams_keep_their_own_generator_state(ctx):
-    """>= 192 solves run as two sub-batches on two streams: each needs its own generator buffers (the host prepares
+    """>= 64 solves run as two sub-batches on two streams: each needs its own generator buffers (the host prepares
     the second while the first still reads its states).  Same bits as the host-drawn path, with a psi large enough
     for the perturbation to reach the leading digits."""
     from adaptive_matrix_solver_amd._cabi import PERT_MT19937, PERT_UNIFORM
