@@ -29,6 +29,11 @@ __global__ void __launch_bounds__(512, 2) fat_kernel(double* out, int iters) {  
     if (s == 12345.678) out[blockIdx.x] = s;
 }
 
+__global__ void __launch_bounds__(512, 4) half_kernel(double* out, int iters) {       // <= 128 VGPRs, 8 waves: half a CU
+    double s = burn<48>(threadIdx.x * 1e-3, iters);
+    if (s == 12345.678) out[blockIdx.x] = s;
+}
+
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main() {
@@ -69,6 +74,23 @@ int main() {
         double all_done = now_ms() - t0;
         printf("mode %d (fat prio %s, thin prio %s): fat alone %.2f ms, thin alone %.2f ms; together: fat finished %.2f ms after its launch, both done after %.2f ms\n",
                mode, mode >= 1 ? "high" : "normal", mode == 2 ? "low" : "normal", fat_alone, thin_alone, fat_done, all_done);
+        // the same with half-CU workgroups (8 waves x <= 128 VGPRs)
+        t0 = now_ms();
+        hipLaunchKernelGGL(half_kernel, dim3(136), dim3(512), 0, sFat, d, 4000);
+        hipStreamSynchronize(sFat);
+        double half_alone = now_ms() - t0;
+        t0 = now_ms();
+        hipLaunchKernelGGL(thin_kernel, dim3(200000), dim3(256), 0, sThin, d, 600);
+        hipEventRecord(eThin, sThin);
+        while (now_ms() - t0 < 2.0) { }
+        tf0 = now_ms();
+        hipLaunchKernelGGL(half_kernel, dim3(136), dim3(512), 0, sFat, d, 4000);
+        hipEventRecord(eFat, sFat);
+        hipEventSynchronize(eFat);
+        double half_done = now_ms() - tf0;
+        hipEventSynchronize(eThin);
+        printf("        half-CU workgroups: alone %.2f ms; beside the thin grid finished %.2f ms after launch, both done after %.2f ms\n",
+               half_alone, half_done, now_ms() - t0);
         hipStreamDestroy(sThin); hipStreamDestroy(sFat);
     }
     return 0;
