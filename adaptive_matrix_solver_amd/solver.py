@@ -364,6 +364,15 @@ class MAUS_Solver:
         self._cond_device = device if (engine is None and cond_exact_max is not None) else None
         self._cond_exact_max = cond_exact_max
         self.diag_info = self._diagnose_matrix_initial(self.M)
+        if comm is not None:
+            # every rank diagnosed the matrix on its own GPU; rank 0's numbers are authoritative so that the strategy --
+            # and with it the sequence of collectives -- cannot diverge between ranks
+            rec = np.array([[float(self.diag_info["condition_number"]), float(self.diag_info["is_singular"]),
+                             float(self.diag_info.get("condition_number_is_estimate", False))]])
+            allr = comm.allgather_rows(rec, [1] * comm.world)
+            self.diag_info["condition_number"] = float(allr[0, 0])
+            self.diag_info["is_singular"] = bool(allr[0, 1])
+            self.diag_info["condition_number_is_estimate"] = bool(allr[0, 2])
         self.is_sparse_problem_init = self.diag_info["is_sparse_init"]
         self.cond_number = self.diag_info["condition_number"]
         self.problem_knowledge = {
