@@ -108,3 +108,32 @@ def test_gram_block_matches_numpy(ctx, count, n):
     ref = X.conj() @ X.T
     assert np.abs(G - ref).max() <= 4e-16 * np.sqrt(n) * (np.abs(X) @ np.abs(X).T).max()
     assert np.allclose(np.diag(G).imag, 0.0, atol=1e-13 * n)
+
+
+def test_empty_and_minimal_inputs(ctx):
+    """count = 0 is a no-op for every batched entry point; n = 1 and n = 2 work (padding to 32, panels of height 32)."""
+    from adaptive_matrix_solver_amd._cabi import KIND_EIG, PERT_NONE
+    rng = np.random.default_rng(0)
+    for n in (1, 2):
+        A = crand(rng, n, n) + 3.0 * np.eye(n)
+        ctx.set_matrix(A)
+        ctx.pop_reserve(4)
+        V = crand(rng, 3, n)
+        ctx.pop_put(0, [0, 1, 2], V)
+        empty = np.zeros(0, dtype=np.int32)
+        num, den = ctx.matvec_rayleigh(empty)
+        assert num.shape == (0,) and den.shape == (0,)
+        assert ctx.shifted_lu_solve(empty, np.zeros(0, complex), np.zeros(0)).shape == (0,)
+        assert ctx.relax_normalise(empty, np.zeros(0, complex)).shape == (0,)
+        res, fin = ctx.residual(KIND_EIG, empty, np.zeros(0, complex))
+        assert res.shape == (0,) and fin.shape == (0,)
+        assert ctx.gram(0, empty, n).shape == (0, 0)
+        lam = np.array([0.1, -0.2j, 0.3 + 0.1j])
+        st = ctx.shifted_lu_solve([0, 1, 2], lam, np.zeros(3), 0, PERT_NONE)
+        assert (st == 0).all()
+        W = ctx.pop_get(2, [0, 1, 2], n)
+        for k in range(3):
+            ref = np.linalg.solve(A - lam[k] * np.eye(n), V[k])
+            assert np.allclose(W[k], ref, rtol=1e-13, atol=1e-14)
+        num, den = ctx.matvec_rayleigh([0, 1, 2])
+        assert np.allclose(num, np.einsum("ki,ki->k", V.conj(), V @ A.T)) and np.allclose(den, np.einsum("ki,ki->k", V.conj(), V))
