@@ -524,30 +524,31 @@ laswp_kernel(c128* __restrict__ Hg, long ld, long strideH, const int* __restrict
 }
 
 // ---------------------------------------------------------------------------------------
-// B <- L11^-1 B with L11 the 32x32 unit-lower block at (j, j), B = rows j..j+32, cols [c_lo,c_hi).
+// B <- L11^-1 B with L11 the TW x TW unit-lower block at (j, j), B = rows j..j+TW, cols [c_lo,c_hi); TW = 16 or 32.
 // One thread per column, L11 broadcast from LDS.
 // ---------------------------------------------------------------------------------------
+template <int TW>
 __global__ void __launch_bounds__(256)
 trsm32_kernel(c128* __restrict__ Hg, long ld, long strideH, int j, int c_lo, int c_hi)
 {
-    __shared__ c128 sL[NBP][NBP + 1];
+    __shared__ c128 sL[TW][TW + 1];
     c128* H = Hg + (long)blockIdx.y * strideH;
-    for (int e = threadIdx.x; e < NBP * NBP; e += blockDim.x) {
-        int r = e / NBP, c = e % NBP;
+    for (int e = threadIdx.x; e < TW * TW; e += blockDim.x) {
+        int r = e / TW, c = e % TW;
         sL[r][c] = H[(long)(j + r) * ld + j + c];
     }
     __syncthreads();
     const int col = c_lo + blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= c_hi) return;
-    c128 x[NBP];
+    c128 x[TW];
 #pragma unroll
-    for (int i = 0; i < NBP; ++i) x[i] = H[(long)(j + i) * ld + col];
+    for (int i = 0; i < TW; ++i) x[i] = H[(long)(j + i) * ld + col];
 #pragma unroll
-    for (int i = 1; i < NBP; ++i)
+    for (int i = 1; i < TW; ++i)
 #pragma unroll
         for (int q = 0; q < i; ++q) cfms(x[i], sL[i][q], x[q]);
 #pragma unroll
-    for (int i = 1; i < NBP; ++i) H[(long)(j + i) * ld + col] = x[i];
+    for (int i = 1; i < TW; ++i) H[(long)(j + i) * ld + col] = x[i];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -637,11 +638,14 @@ static void lu_laswp(const LuWs& w, int k1, int k2, int c_lo, int c_hi) {
 
 static void lu_trsm(const LuWs& w, int j, int k, int c_lo, int c_hi) {
     if (c_hi <= c_lo) return;
-    if (k <= NBP) {
+    // base: one thread per column holds the 16 or 32 rows in registers (32 saves the level of 16-row zgemm updates)
+    static const int tw32 = [] { const char* e = getenv("MAUS_TRSM32"); return e ? atoi(e) : 1; }();
+    if (k <= NBP || (tw32 && k == 32)) {
         prof(w, KC_TRSM, 0);
         dim3 grid((c_hi - c_lo + 255) / 256, w.G);
-        hipLaunchKernelGGL(trsm32_kernel, grid, dim3(256), 0, w.st, w.H, w.ldh, w.strideH, j, c_lo, c_hi);
-        prof(w, KC_TRSM, 1, 4.0 * NBP * NBP * (c_hi - c_lo) * w.G, 32.0 * NBP * (c_hi - c_lo) * w.G);
+        if (k == 32 && NBP < 32) hipLaunchKernelGGL((trsm32_kernel<32>), grid, dim3(256), 0, w.st, w.H, w.ldh, w.strideH, j, c_lo, c_hi);
+        else hipLaunchKernelGGL((trsm32_kernel<NBP>), grid, dim3(256), 0, w.st, w.H, w.ldh, w.strideH, j, c_lo, c_hi);
+        prof(w, KC_TRSM, 1, 4.0 * k * k * (c_hi - c_lo) * w.G, 32.0 * k * (c_hi - c_lo) * w.G);
         return;
     }
     int h = (k >= 2 * NBP) ? (k / (2 * NBP)) * NBP : NBP;
