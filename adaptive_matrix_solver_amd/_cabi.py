@@ -19,7 +19,7 @@ SYMBOLS = [
     "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get",
     "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_relax_normalise", "maus_residual",
     "maus_svd_power_step", "maus_set_eigvecs", "maus_herm_match", "maus_gmres", "maus_jacobi_check",
-    "maus_gram", "maus_zgemm_host", "maus_zgemm_bench", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
+    "maus_profile_union_ms", "maus_gram", "maus_zgemm_host", "maus_zgemm_bench", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
     "maus_profile_enable", "maus_profile_read", "maus_sync", "maus_mt19937_jump",
 ]
 
@@ -77,6 +77,7 @@ def load_library():
         "maus_herm_match": ([vp, vp, C.c_int, vp, vp], C.c_int),
         "maus_gmres": ([vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_int, C.c_int, vp, vp, vp], C.c_int),
         "maus_jacobi_check": ([vp, C.c_int, vp, vp, vp], C.c_int),
+        "maus_profile_union_ms": ([vp, C.c_int, C.POINTER(C.c_double)], C.c_int),
         "maus_gram": ([vp, C.c_int, vp, C.c_int, C.c_int, vp], C.c_int),
         "maus_zgemm_host": ([vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int], C.c_int),
         "maus_lu_solve_host": ([vp, C.c_int, C.c_int, vp, vp, vp, vp, vp], C.c_int),
@@ -166,7 +167,9 @@ class Context:
             n = C.c_int()
             ms, fl, by = C.c_double(), C.c_double(), C.c_double()
             self._ck(self.lib.maus_profile_read(self.h, k, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "maus_profile_read")
-            out[name] = {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+            un = C.c_double()
+            self._ck(self.lib.maus_profile_union_ms(self.h, k, C.byref(un)), "maus_profile_union_ms")
+            out[name] = {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value, "union_ms": un.value}
         return out
 
     # -- problem data --------------------------------------------------------

@@ -76,6 +76,10 @@ static void prof_resolve(maus_ctx* c) {
     (void)hipStreamSynchronize(c->st);
     for (auto& r : c->pending) {
         float ms = 0.f; (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (c->prof_origin) {                            // interval on the common clock, for the union over both streams
+            float t0 = 0.f;
+            if (hipEventElapsedTime(&t0, c->prof_origin, r.e0) == hipSuccess) c->prof_iv[r.klass].push_back({t0, t0 + ms});
+        }
         c->launches[r.klass] += (long)r.weight; c->ms[r.klass] += ms * r.weight; c->flops[r.klass] += r.flops * r.weight;
         c->bytes[r.klass] += r.bytes * r.weight;
         c->pool.push_back(r.e0); c->pool.push_back(r.e1);
@@ -118,6 +122,7 @@ int maus_ctx_destroy(maus_ctx* c) {
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->prof_origin) (void)hipEventDestroy(c->prof_origin);
     (void)hipStreamDestroy(c->st);
     delete c;
     return 0;
@@ -706,10 +711,35 @@ int maus_profile_enable(maus_ctx* c, int on) {
     c->prof_seq = 0;
     for (int k = 0; k < KC_COUNT; ++k) c->prof_cnt[k] = 0;
     if (const char* e = getenv("MAUS_PROF_STRIDE")) {           // "big,small"
-        int a = 5, b = 0;
+        int a = 1, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) >= 1) { c->prof_stride_big = std::max(1, a); c->prof_stride_small = std::max(0, b); }
     }
-    if (on) for (int k = 0; k < KC_COUNT; ++k) { c->launches[k] = 0; c->ms[k] = 0; c->flops[k] = 0; c->bytes[k] = 0; c->total_launches[k] = 0; }
+    if (on) for (int k = 0; k < KC_COUNT; ++k) { c->launches[k] = 0; c->ms[k] = 0; c->flops[k] = 0; c->bytes[k] = 0; c->total_launches[k] = 0; c->prof_iv[k].clear(); }
+    if (on) {
+        if (!c->prof_origin) HIPCHK(c, hipEventCreate(&c->prof_origin));
+        HIPCHK(c, hipEventRecord(c->prof_origin, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+    }
+    return 0;
+}
+
+// Length (ms) of the UNION of the bracketed launches' time intervals of one class, over every stream they ran on:
+// the time during which at least one such kernel was executing.  With sub-batches on two streams two trailing updates
+// often run side by side and share the machine; their flops divided by this union is the rate the class achieved,
+// whereas the sum of the individual durations counts the shared time twice.
+int maus_profile_union_ms(maus_ctx* c, int klass, double* union_ms) {
+    if (klass < 0 || klass >= KC_COUNT || !union_ms) FAIL(c, "maus_profile_union_ms: bad arguments");
+    prof_resolve(c);
+    auto iv = c->prof_iv[klass];
+    std::sort(iv.begin(), iv.end());
+    double tot = 0.0; float cs = 0.f, ce = -1.f;
+    for (auto& p : iv) {
+        if (ce < 0.f) { cs = p.first; ce = p.second; }
+        else if (p.first <= ce) ce = std::max(ce, p.second);
+        else { tot += ce - cs; cs = p.first; ce = p.second; }
+    }
+    if (ce >= 0.f) tot += ce - cs;
+    *union_ms = tot;
     return 0;
 }
 

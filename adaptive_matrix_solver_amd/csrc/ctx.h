@@ -78,7 +78,9 @@ struct maus_ctx {
     bool prof_on = false;
     int prof_mode = 1;            // 1: every launch of every class; 2: every 5th launch of the zgemm classes only
     long prof_seq = 0; bool prof_skip = false;
-    long prof_cnt[KC_COUNT] = {0}; int prof_stride_big = 5, prof_stride_small = 0; double prof_weight = 1.0;
+    long prof_cnt[KC_COUNT] = {0}; int prof_stride_big = 1, prof_stride_small = 0; double prof_weight = 1.0;
+    hipEvent_t prof_origin = nullptr;                   // recorded on `st` when profiling is switched on
+    std::vector<std::pair<float, float>> prof_iv[KC_COUNT];   // [start, end] ms since prof_origin of every bracketed launch
     int total_launches[KC_COUNT] = {0};
     std::vector<ProfRec> pending;
     std::vector<hipEvent_t> pool;

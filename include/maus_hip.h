@@ -170,6 +170,9 @@ int maus_timer_stop(maus_ctx* ctx, float* ms_out);
  * enough for a timed region: full bracketing costs 3-5 % of throughput); 0: off */
 int maus_profile_enable(maus_ctx* ctx, int on);
 int maus_profile_read(maus_ctx* ctx, int klass, int* launches, double* total_ms, double* flops, double* bytes);
+/* ms during which at least one bracketed launch of the class was executing (union of their intervals over all
+ * streams; equals total_ms when nothing overlaps) */
+int maus_profile_union_ms(maus_ctx* ctx, int klass, double* union_ms);
 int maus_sync(maus_ctx* ctx);
 
 /* Device-resident timing of the batched LU-update GEMM shape (C[M,N] -= A[M,K] B[K,N] on `batch` matrices
