@@ -166,8 +166,9 @@ int maus_timer_stop(maus_ctx* ctx, float* ms_out);
 /* Per-kernel-class accounting (event pairs around each launch of the class while enabled).
  * classes: 0 zgemm (LU trailing update with K>=256 / A@X), 1 lu_panel, 2 trsm, 3 laswp, 4 build_H, 5 backsolve,
  * 6 vector ops, 7..10 zgemm inside the LU recursion with K = 128 / 64 / 32 / 16 */
-/* on = 1: event pairs around every launch; on = 2: around every 5th launch of the zgemm classes only (cheap
- * enough for a timed region: full bracketing costs 3-5 % of throughput); 0: off */
+/* on = 1: event pairs around every launch of every class; on = 2: around the K>=256 zgemm launches only (class 0;
+ * long kernels, so cheap enough for a timed region -- full bracketing costs 3-5 % of throughput; MAUS_PROF_STRIDE
+ * can thin them out, each sample then stands for `stride` launches); 0: off */
 int maus_profile_enable(maus_ctx* ctx, int on);
 int maus_profile_read(maus_ctx* ctx, int klass, int* launches, double* total_ms, double* flops, double* bytes);
 /* ms during which at least one bracketed launch of the class was executing (union of their intervals over all
