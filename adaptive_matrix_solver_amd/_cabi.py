@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmaus_hip.so")
 SYMBOLS = [
     "maus_ctx_create", "maus_ctx_destroy", "maus_last_error", "maus_device_info", "maus_abi_version",
     "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get",
-    "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_relax_normalise", "maus_residual",
+    "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_lu_reserve", "maus_lu_workspace_allocs", "maus_relax_normalise", "maus_residual",
     "maus_svd_power_step", "maus_set_eigvecs", "maus_herm_match", "maus_gmres", "maus_jacobi_check",
     "maus_profile_union_ms", "maus_gram", "maus_zgemm_host", "maus_zgemm_bench", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
     "maus_profile_enable", "maus_profile_read", "maus_sync", "maus_mt19937_jump",
@@ -70,6 +70,8 @@ def load_library():
         "maus_pop_get": ([vp, C.c_int, vp, C.c_int, vp, C.c_int], C.c_int),
         "maus_matvec_rayleigh": ([vp, vp, C.c_int, vp, vp], C.c_int),
         "maus_shifted_lu_solve": ([vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp], C.c_int),
+        "maus_lu_reserve": ([vp, C.c_int, C.c_int, ip], C.c_int),
+        "maus_lu_workspace_allocs": ([vp], C.c_int),
         "maus_relax_normalise": ([vp, vp, C.c_int, vp, C.c_int, vp], C.c_int),
         "maus_residual": ([vp, C.c_int, vp, C.c_int, vp, vp, vp], C.c_int),
         "maus_svd_power_step": ([vp, vp, C.c_int, vp], C.c_int),
@@ -161,16 +163,18 @@ class Context:
     def profile_enable(self, on=True):
         self._ck(self.lib.maus_profile_enable(self.h, int(on)), "maus_profile_enable")
 
+    def profile_read_class(self, k):
+        n = C.c_int()
+        ms, fl, by, un = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        self._ck(self.lib.maus_profile_read(self.h, k, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "maus_profile_read")
+        self._ck(self.lib.maus_profile_union_ms(self.h, k, C.byref(un)), "maus_profile_union_ms")
+        return {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value, "union_ms": un.value}
+
     def profile_read(self):
-        out = {}
-        for k, name in enumerate(KC_NAMES):
-            n = C.c_int()
-            ms, fl, by = C.c_double(), C.c_double(), C.c_double()
-            self._ck(self.lib.maus_profile_read(self.h, k, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "maus_profile_read")
-            un = C.c_double()
-            self._ck(self.lib.maus_profile_union_ms(self.h, k, C.byref(un)), "maus_profile_union_ms")
-            out[name] = {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value, "union_ms": un.value}
-        return out
+        return {name: self.profile_read_class(k) for k, name in enumerate(KC_NAMES)}
+
+    def lu_workspace_allocations(self) -> int:
+        return int(self.lib.maus_lu_workspace_allocs(self.h))
 
     # -- problem data --------------------------------------------------------
     def set_matrix(self, A):
@@ -246,6 +250,12 @@ class Context:
         self._ck(self.lib.maus_shifted_lu_solve(self.h, _ptr(s), k, _ptr(sh), _ptr(ps), int(rhs_mode), int(pert_mode),
                                                 pdp, _ptr(status)), "maus_shifted_lu_solve")
         return status
+
+    def lu_reserve(self, n, count) -> int:
+        """Size the LU workspace once for `count` simultaneous n x n solves; returns its capacity in matrices."""
+        cap = C.c_int()
+        self._ck(self.lib.maus_lu_reserve(self.h, int(n), int(count), C.byref(cap)), "maus_lu_reserve")
+        return int(cap.value)
 
     def relax_normalise(self, slots, alpha, normalise=True):
         s = self._slots(slots)

@@ -264,6 +264,10 @@ int maus_matvec_rayleigh(maus_ctx* c, const int* slots, int count, double* num, 
     return 0;
 }
 
+// LU workspace for `want` simultaneous n x n systems.  Sized geometrically and never shrunk: a hipFree + hipMalloc of
+// ~100 GB costs seconds, so a workspace that follows the batch size step by step (the eig population grows by up to 15
+// candidates per iteration, AMS:533-534) would re-allocate inside somebody's timed region.  Callers that know their
+// population announce it with maus_lu_reserve(); batches beyond the workspace run in chunks.
 static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     int npad = round_up(n, 32);
     if (npad > maus_lu_max_npad()) FAIL(c, "direct LU path supports n <= 8192 in this build");
@@ -275,19 +279,23 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     int gmax = (int)std::max<size_t>(1, (size_t)(fr * 0.80) / per);
     const char* env = getenv("MAUS_LU_BATCH");
     int cap = env ? std::max(1, atoi(env)) : 512;
-    // head room: the population grows by a few spawned candidates per iteration, and re-allocating tens of GB costs seconds
-    int G = std::min(std::min(round_up(want + want / 4, 32), cap), gmax);
+    int G = round_up(want, 32);
+    if (c->H && c->Hnpad == npad) G = std::max(G, 2 * c->Hg);          // grow at least two-fold
+    G = std::min(std::min(G, cap), gmax);
     if (c->H && c->Hnpad == npad && c->Hg >= G) return 0;
     HIPCHK(c, hipStreamSynchronize(c->st));
+    for (auto st : c->lu_st) HIPCHK(c, hipStreamSynchronize(st));
     if (c->H) { (void)hipFree(c->H); c->H = nullptr; }
     if (c->ipiv) { (void)hipFree(c->ipiv); c->ipiv = nullptr; }
     if (c->info) { (void)hipFree(c->info); c->info = nullptr; }
     if (c->flags) { (void)hipFree(c->flags); c->flags = nullptr; }
+    c->Hg = 0; c->Hbytes = 0;
     HIPCHK(c, hipMalloc((void**)&c->H, per * G));
     HIPCHK(c, hipMalloc((void**)&c->ipiv, sizeof(int) * (size_t)G * npad));
     HIPCHK(c, hipMalloc((void**)&c->info, sizeof(int) * G));
     HIPCHK(c, hipMalloc((void**)&c->flags, sizeof(int) * G));
     c->Hbytes = per * G; c->Hg = G; c->Hnpad = npad;
+    c->ws_allocs++;
     return 0;
 }
 
@@ -532,6 +540,15 @@ int maus_lu_solve_host(maus_ctx* c, int count, int n, const double* a, const dou
     }
     return 0;
 }
+
+int maus_lu_reserve(maus_ctx* c, int n, int count, int* capacity_out) {
+    if (n <= 0 || count < 0) FAIL(c, "maus_lu_reserve: bad sizes");
+    if (count > 0 && ensure_lu_ws(c, n, count)) return -1;
+    if (capacity_out) *capacity_out = (c->H && c->Hnpad == round_up(n, 32)) ? c->Hg : 0;
+    return 0;
+}
+
+int maus_lu_workspace_allocs(maus_ctx* c) { return c ? c->ws_allocs : -1; }
 
 int maus_relax_normalise(maus_ctx* c, const int* slots, int count, const double* alpha, int normalise, double* norm_out) {
     if (!c->X) FAIL(c, "maus_relax_normalise: population missing");

@@ -57,7 +57,7 @@ struct maus_ctx {
     c128 *d_c1 = nullptr, *d_c2 = nullptr;
     double *d_r1 = nullptr, *d_r2 = nullptr;
     // LU workspace
-    c128* H = nullptr; size_t Hbytes = 0; int Hg = 0; int Hnpad = 0;
+    c128* H = nullptr; size_t Hbytes = 0; int Hg = 0; int Hnpad = 0; int ws_allocs = 0;
     int *ipiv = nullptr, *info = nullptr, *flags = nullptr;
     double* Upert = nullptr; size_t Ubytes = 0;
     // device-side MT19937 regeneration (mtdev.hip)

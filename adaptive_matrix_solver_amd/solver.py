@@ -350,7 +350,8 @@ class SolutionCandidate:
 class MAUS_Solver:
     def __init__(self, problem_matrix, problem_type, b_vector=None, initial_num_candidates=None,
                  global_convergence_tol=1e-8, *, device=0, pert_mode="auto", gmres_compat="rtol",
-                 record_history=None, comm=None, quiet=False, engine=None, gram_min=8, cond_exact_max=1024):
+                 record_history=None, comm=None, quiet=False, engine=None, gram_min=8, cond_exact_max=1024,
+                 diag_info=None):
         if _is_sparse(problem_matrix):
             raise NotImplementedError("sparse problems are outside the MI355X hot path (dense only)")
         self.M = problem_matrix.astype(np.complex128)                                   # AMS:343
@@ -363,8 +364,9 @@ class MAUS_Solver:
         # seam) keeps the reference's exact computation
         self._cond_device = device if (engine is None and cond_exact_max is not None) else None
         self._cond_exact_max = cond_exact_max
-        self.diag_info = self._diagnose_matrix_initial(self.M)
-        if comm is not None:
+        # `diag_info`: start-up diagnostics of the same matrix taken from an earlier solver (bench side runs)
+        self.diag_info = dict(diag_info) if diag_info is not None else self._diagnose_matrix_initial(self.M)
+        if comm is not None and diag_info is None:
             # every rank diagnosed the matrix on its own GPU; rank 0's numbers are authoritative so that the strategy --
             # and with it the sequence of collectives -- cannot diverge between ranks
             rec = np.array([[float(self.diag_info["condition_number"]), float(self.diag_info["is_singular"]),

@@ -104,6 +104,17 @@ int maus_shifted_lu_solve(maus_ctx* ctx, const int* slots, int count, const doub
                           const double* psi, int rhs_mode, int pert_mode, const void* pert_data,
                           int32_t* status);
 
+/* Size the LU workspace ONCE for up to `count` simultaneous n x n systems (the reference's sla.solve allocates its
+ * copy of H per call, AMS:59; here H_k of a whole batch are device-resident, 270 MB each at n = 4096, and re-allocating
+ * ~100 GB costs seconds).  Capped by 80 % of the free HBM and MAUS_LU_BATCH (default 512); larger batches run in
+ * chunks.  The workspace never shrinks and otherwise grows at least two-fold on demand.  capacity_out (may be NULL):
+ * matrices the workspace holds after the call. */
+int maus_lu_reserve(maus_ctx* ctx, int n, int count, int* capacity_out);
+
+/* Number of times the LU workspace has been (re-)allocated on this context (measurement: a timed region must not
+ * contain one). */
+int maus_lu_workspace_allocs(maus_ctx* ctx);
+
 /* X[slot] <- (1-alpha) X[slot] + alpha W[slot]; norm_out = ||X||_2; if normalise and
  * norm > 1e-10: X *= 1/norm                                        AMS:280-285.
  * alpha_c128[count] complex.  Slots whose norm test fails are left un-normalised (the
@@ -141,7 +152,7 @@ int maus_gram(maus_ctx* ctx, int which, const int* slots, int count, int len, do
  * scipy/sparse/linalg/_isolve/iterative.py:692-841 (restart 20, MGS, Givens, ptol).
  *   H_k = A - shift_k I + psi_k I (MAUS_PERT_NONE only); x0 = rhs; W[slot] <- x
  * use_jacobi[count]: 1 -> M = diag(1/diag H_k) (caller applies AMS:65/72 gating via
- * jacobi_ok_out of a previous call or maus_diag_check).
+ * maus_jacobi_check below).
  * info_out: 0 converged, maxiter otherwise (SciPy convention); inner_out: inner iterations. */
 int maus_gmres(maus_ctx* ctx, const int* slots, int count, const double* shift_c128, const double* psi,
                int rhs_mode, const int32_t* use_jacobi, double rtol, int restart, int maxiter,

@@ -46,6 +46,9 @@ class FakeContext:
                 self.pop[w] = new
             self.cap = cap
 
+    def lu_reserve(self, n, count):
+        return int(count)
+
     def pop_capacity(self):
         return self.cap
 
