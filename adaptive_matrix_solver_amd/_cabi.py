@@ -16,9 +16,9 @@ LIB_PATH = os.path.join(_HERE, "libmaus_hip.so")
 # every symbol include/maus_hip.h declares (tests/test_cabi_symbols.py checks the list against the header)
 SYMBOLS = [
     "maus_ctx_create", "maus_ctx_destroy", "maus_last_error", "maus_device_info", "maus_abi_version",
-    "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get",
+    "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get", "maus_pop_copy",
     "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_lu_reserve", "maus_lu_workspace_allocs", "maus_relax_normalise", "maus_residual",
-    "maus_svd_power_step", "maus_set_eigvecs", "maus_herm_match", "maus_gmres", "maus_jacobi_check",
+    "maus_svd_power_step", "maus_set_eigvecs", "maus_herm_match", "maus_gmres", "maus_gmres_pert", "maus_jacobi_check",
     "maus_profile_union_ms", "maus_gram", "maus_zgemm_host", "maus_zgemm_bench", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
     "maus_profile_enable", "maus_profile_read", "maus_sync", "maus_mt19937_jump",
 ]
@@ -68,6 +68,7 @@ def load_library():
         "maus_pop_capacity": ([vp], C.c_int),
         "maus_pop_put": ([vp, C.c_int, vp, C.c_int, vp, C.c_int], C.c_int),
         "maus_pop_get": ([vp, C.c_int, vp, C.c_int, vp, C.c_int], C.c_int),
+        "maus_pop_copy": ([vp, C.c_int, C.c_int, vp, C.c_int], C.c_int),
         "maus_matvec_rayleigh": ([vp, vp, C.c_int, vp, vp], C.c_int),
         "maus_shifted_lu_solve": ([vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp], C.c_int),
         "maus_lu_reserve": ([vp, C.c_int, C.c_int, ip], C.c_int),
@@ -78,6 +79,7 @@ def load_library():
         "maus_set_eigvecs": ([vp, vp, C.c_int], C.c_int),
         "maus_herm_match": ([vp, vp, C.c_int, vp, vp], C.c_int),
         "maus_gmres": ([vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_int, C.c_int, vp, vp, vp], C.c_int),
+        "maus_gmres_pert": ([vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, C.c_double, C.c_int, C.c_int, vp, vp, vp, vp], C.c_int),
         "maus_jacobi_check": ([vp, C.c_int, vp, vp, vp], C.c_int),
         "maus_profile_union_ms": ([vp, C.c_int, C.POINTER(C.c_double)], C.c_int),
         "maus_gram": ([vp, C.c_int, vp, C.c_int, C.c_int, vp], C.c_int),
@@ -216,6 +218,10 @@ class Context:
         self._ck(self.lib.maus_pop_get(self.h, which, _ptr(s), s.shape[0], _ptr(out), length), "maus_pop_get")
         return out
 
+    def pop_copy(self, which_dst, which_src, slots):
+        s = self._slots(slots)
+        self._ck(self.lib.maus_pop_copy(self.h, int(which_dst), int(which_src), _ptr(s), s.shape[0]), "maus_pop_copy")
+
     # -- phases --------------------------------------------------------------
     def matvec_rayleigh(self, slots):
         s = self._slots(slots)
@@ -224,20 +230,13 @@ class Context:
         self._ck(self.lib.maus_matvec_rayleigh(self.h, _ptr(s), s.shape[0], _ptr(num), _ptr(den)), "maus_matvec_rayleigh")
         return num, den
 
-    def shifted_lu_solve(self, slots, shift, psi, rhs_mode=0, pert_mode=PERT_NONE, pert_data=None):
-        s = self._slots(slots)
-        k = s.shape[0]
-        sh = _c128(shift, (k,))
-        ps = np.ascontiguousarray(psi, dtype=np.float64)
-        assert ps.shape == (k,)
-        status = np.zeros(k, dtype=np.int32)
-        pd = None
-        pdp = None
+    def _pert_arg(self, k, pert_mode, pert_data):
+        """(keep-alive objects, void*) for the pert_data argument of the solve entry points."""
         if pert_mode == PERT_UNIFORM:
             pd = np.ascontiguousarray(pert_data, dtype=np.float64)
             assert pd.shape == (k, 2, self.rows, self.rows), pd.shape
-            pdp = _ptr(pd)
-        elif pert_mode == PERT_MT19937:
+            return (pd,), _ptr(pd)
+        if pert_mode == PERT_MT19937:
             # pert_data = (numpy_state, words_per_candidate, lead_words, ordinals)
             st, wpc, lead, ords = pert_data
             ords = np.ascontiguousarray(ords, dtype=np.int32)
@@ -246,7 +245,17 @@ class Context:
             C.memmove(pd.key, np.ascontiguousarray(st[1], dtype=np.uint32).ctypes.data, 624 * 4)
             pd.pos = int(st[2]); pd.words_per_candidate = int(wpc); pd.lead_words = int(lead)
             pd.ordinals = ords.ctypes.data_as(C.POINTER(C.c_int32))
-            pdp = C.cast(C.pointer(pd), C.c_void_p)
+            return (pd, ords), C.cast(C.pointer(pd), C.c_void_p)
+        return (), None
+
+    def shifted_lu_solve(self, slots, shift, psi, rhs_mode=0, pert_mode=PERT_NONE, pert_data=None):
+        s = self._slots(slots)
+        k = s.shape[0]
+        sh = _c128(shift, (k,))
+        ps = np.ascontiguousarray(psi, dtype=np.float64)
+        assert ps.shape == (k,)
+        status = np.zeros(k, dtype=np.int32)
+        keep, pdp = self._pert_arg(k, pert_mode, pert_data)
         self._ck(self.lib.maus_shifted_lu_solve(self.h, _ptr(s), k, _ptr(sh), _ptr(ps), int(rhs_mode), int(pert_mode),
                                                 pdp, _ptr(status)), "maus_shifted_lu_solve")
         return status
@@ -306,6 +315,23 @@ class Context:
         self._ck(self.lib.maus_gmres(self.h, _ptr(s), k, _ptr(sh), _ptr(ps), int(rhs_mode), _ptr(uj), float(rtol),
                                      int(restart), int(maxiter), _ptr(info), _ptr(inner), _ptr(status)), "maus_gmres")
         return info, inner, status
+
+    def gmres_pert(self, slots, shift, psi, rhs_mode, want_jacobi, pert_mode, pert_data, rtol=1e-8, restart=20, maxiter=50):
+        """GMRES against the materialised H_k including the random term of AMS:49-50 -> (info, inner, status, jacobi_used)."""
+        s = self._slots(slots)
+        k = s.shape[0]
+        sh = _c128(shift, (k,))
+        ps = np.ascontiguousarray(psi, dtype=np.float64)
+        wj = np.ascontiguousarray(want_jacobi, dtype=np.int32)
+        info = np.zeros(k, dtype=np.int32)
+        inner = np.zeros(k, dtype=np.int32)
+        status = np.zeros(k, dtype=np.int32)
+        jac = np.zeros(k, dtype=np.int32)
+        keep, pdp = self._pert_arg(k, pert_mode, pert_data)
+        self._ck(self.lib.maus_gmres_pert(self.h, _ptr(s), k, _ptr(sh), _ptr(ps), int(rhs_mode), _ptr(wj), int(pert_mode), pdp,
+                                          float(rtol), int(restart), int(maxiter), _ptr(info), _ptr(inner), _ptr(status),
+                                          _ptr(jac)), "maus_gmres_pert")
+        return info, inner, status, jac.astype(bool)
 
     def jacobi_check(self, shift, psi):
         sh = _c128(shift)

@@ -111,7 +111,7 @@ int maus_ctx_destroy(maus_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
     void* ptrs[] = {c->A, c->b, c->V, c->X, c->U, c->W, c->Y, c->d_slots, c->d_i1, c->d_i2, c->d_c1, c->d_c2, c->d_r1, c->d_r2,
-                    c->H, c->ipiv, c->info, c->flags, c->Upert, c->scratch};
+                    c->H, c->ipiv, c->perm, c->info, c->flags, c->Upert, c->scratch};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : c->mt_taps) if (kv.second.first) (void)hipFree(kv.second.first);
     for (auto& b : c->mt_bufs) { if (b.states) (void)hipFree(b.states); if (b.ints) (void)hipFree(b.ints); if (b.base) (void)hipFree(b.base); }
@@ -243,6 +243,21 @@ int maus_pop_get(maus_ctx* c, int which, const int* slots, int count, double* ho
     return 0;
 }
 
+__global__ void copy_rows_kernel(c128* __restrict__ dst, const c128* __restrict__ src, long ld, const int* __restrict__ slots, int len) {
+    const long o = (long)slots[blockIdx.x] * ld;
+    for (int k = threadIdx.x; k < len; k += blockDim.x) dst[o + k] = src[o + k];
+}
+
+int maus_pop_copy(maus_ctx* c, int which_dst, int which_src, const int* slots, int count) {
+    c128* D = pop_array(c, which_dst); c128* S = pop_array(c, which_src);
+    if (!D || !S || D == S) FAIL(c, "maus_pop_copy: population not reserved / bad array ids");
+    if (count == 0) return 0;
+    if (upload_slots(c, slots, count)) return -1;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(count), dim3(256), 0, c->st, D, S, c->ldp, c->d_slots, (int)c->ldp);
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
 // Y[slot] = A @ X[slot] for all listed slots:  C[count, rows] = Xg[count, cols] * A^T  (A as [n][k])
 static void matvec_into_Y(maus_ctx* c, const c128* src, int count) {
     ProfScope ps(c, KC_GEMM, 8.0 * count * c->rows * c->cols, 16.0 * ((double)c->rows * c->cols + 2.0 * count * c->ldp));
@@ -271,7 +286,7 @@ int maus_matvec_rayleigh(maus_ctx* c, const int* slots, int count, double* num, 
 static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     int npad = round_up(n, 32);
     if (npad > maus_lu_max_npad()) FAIL(c, "direct LU path supports n <= 8192 in this build");
-    size_t per = sizeof(c128) * (size_t)npad * (npad + 32);
+    size_t per = 2 * sizeof(c128) * (size_t)npad * (npad + 32);    // H and the logical-order U array (implicit pivoting)
     if (c->H && c->Hnpad == npad && c->Hg >= want) return 0;
     size_t fr = 0, tot = 0;
     HIPCHK(c, hipMemGetInfo(&fr, &tot));
@@ -287,11 +302,13 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     for (auto st : c->lu_st) HIPCHK(c, hipStreamSynchronize(st));
     if (c->H) { (void)hipFree(c->H); c->H = nullptr; }
     if (c->ipiv) { (void)hipFree(c->ipiv); c->ipiv = nullptr; }
+    if (c->perm) { (void)hipFree(c->perm); c->perm = nullptr; }
     if (c->info) { (void)hipFree(c->info); c->info = nullptr; }
     if (c->flags) { (void)hipFree(c->flags); c->flags = nullptr; }
     c->Hg = 0; c->Hbytes = 0;
     HIPCHK(c, hipMalloc((void**)&c->H, per * G));
     HIPCHK(c, hipMalloc((void**)&c->ipiv, sizeof(int) * (size_t)G * npad));
+    HIPCHK(c, hipMalloc((void**)&c->perm, sizeof(int) * (size_t)G * npad));
     HIPCHK(c, hipMalloc((void**)&c->info, sizeof(int) * G));
     HIPCHK(c, hipMalloc((void**)&c->flags, sizeof(int) * G));
     c->Hbytes = per * G; c->Hg = G; c->Hnpad = npad;
@@ -302,12 +319,13 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
 static LuWs make_ws(maus_ctx* c, int n, int G) {
     LuWs w;
     w.n = n; w.npad = c->Hnpad; w.ldh = w.npad + 32; w.strideH = (long)w.npad * w.ldh; w.G = G;
-    w.H = c->H; w.ipiv = c->ipiv; w.info = c->info; w.flags = c->flags; w.st = c->st;
+    w.H = c->H; w.U = c->H + (size_t)c->Hg * w.strideH; w.perm = c->perm; w.ipiv = c->ipiv; w.info = c->info; w.flags = c->flags; w.st = c->st;
     w.tick = prof_tick; w.ud = c;
     return w;
 }
 
-static int lu_stream_count() { const char* e = getenv("MAUS_LU_STREAMS"); int v = e ? atoi(e) : 2; return std::max(1, std::min(8, v)); }
+// three sub-batch streams: 300 candidate-steps/s against 291 / 290 / 277 / 279 with 1 / 2 / 4 / 6 (driver-shaped run, round 2)
+static int lu_stream_count() { const char* e = getenv("MAUS_LU_STREAMS"); int v = e ? atoi(e) : 3; return std::max(1, std::min(8, v)); }
 
 static int ensure_lu_streams(maus_ctx* c, int n) {
     if (!c->ev_stage) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
@@ -468,9 +486,10 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             dU = c->Upert;
         }
         // Sub-batches on their own streams (at least 32 matrices each): the bandwidth- and latency-bound phases of one
-        // sub-batch (panel, row swaps, triangular solves, H build) run beside the MFMA-bound trailing updates of the
-        // other.  Measured at n=4096, 271 solves: 284 candidate-steps/s with two streams against 268 with one; three
-        // and four streams are slower again, and below ~64 matrices there is nothing to gain.
+        // sub-batch (panel, triangular solves, H build) run beside the MFMA-bound trailing updates of the others.  The gain
+        // is bounded -- a streaming kernel beside the zgemm hides ~30 % of its time at best (tools/probe_corun.hip) --
+        // and more sub-batches mean smaller, less efficient launches: 1 / 2 / 3 / 4 / 6 streams gave 291 / 290 / 300 /
+        // 277 / 279 candidate-steps/s on the driver-shaped run (n=4096, 176-331 solves per step).
         const int S = std::max(1, std::min(nst, G / 32));
         if (S > 1) HIPCHK(c, hipEventRecord(c->ev_stage, c->st));
         std::vector<LuWs> wss;
@@ -481,7 +500,7 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             hipStream_t st = (S == 1) ? c->st : c->lu_st[sb];
             if (S > 1) HIPCHK(c, hipStreamWaitEvent(st, c->ev_stage, 0));
             LuWs w = make_ws(c, n, g);
-            w.H += (long)lo * w.strideH; w.ipiv += (long)lo * w.npad; w.info += lo; w.flags += lo; w.st = st;
+            w.H += (long)lo * w.strideH; w.U += (long)lo * w.strideH; w.perm += (long)lo * w.npad; w.ipiv += (long)lo * w.npad; w.info += lo; w.flags += lo; w.st = st;
             c->prof_st = st;
             if (pert_mode == MAUS_PERT_MT19937) {
                 if (mt_prepare_and_build(c, w, (const maus_mt_desc*)pert_data, off + lo, g, rhs_mode, lo, sb)) return -1;
@@ -658,7 +677,48 @@ int maus_gram(maus_ctx* c, int which, const int* slots, int count, int len, doub
 
 int maus_gmres(maus_ctx* c, const int* slots, int count, const double* shift, const double* psi, int rhs_mode,
                const int32_t* use_jacobi, double rtol, int restart, int maxiter, int32_t* info_out, int32_t* inner_out, int32_t* status) {
-    return maus_gmres_run(c, slots, count, shift, psi, rhs_mode, use_jacobi, rtol, restart, maxiter, info_out, inner_out, status);
+    return maus_gmres_run(c, slots, count, shift, psi, rhs_mode, use_jacobi, rtol, restart, maxiter, info_out, inner_out, status,
+                          nullptr, 0, 0, nullptr);
+}
+
+int maus_gmres_pert(maus_ctx* c, const int* slots, int count, const double* shift, const double* psi, int rhs_mode,
+                    const int32_t* want_jacobi, int pert_mode, const void* pert_data, double rtol, int restart, int maxiter,
+                    int32_t* info_out, int32_t* inner_out, int32_t* status, int32_t* jacobi_out) {
+    if (!c->A || !c->X) FAIL(c, "maus_gmres_pert: matrix/population missing");
+    if (c->rows != c->cols) FAIL(c, "maus_gmres_pert: square matrix required");
+    if (rhs_mode == 1 && (!c->b || c->bn != c->rows)) FAIL(c, "maus_gmres_pert: rhs b not set");
+    if ((pert_mode == MAUS_PERT_UNIFORM || pert_mode == MAUS_PERT_MT19937) && !pert_data) FAIL(c, "pert_data missing");
+    if (count == 0) return 0;
+    const int n = c->rows;
+    if (check_slots(c, slots, count)) return -1;
+    if (ensure_scalars(c, count)) return -1;
+    if (ensure_lu_ws(c, n, count)) return -1;
+    std::vector<int> h_flags(std::min(count, c->Hg));
+    for (int off = 0; off < count; off += c->Hg) {                     // chunks of at most the workspace capacity
+        const int G = std::min(c->Hg, count - off);
+        HIPCHK(c, hipMemcpyAsync(c->d_slots, slots + off, sizeof(int) * G, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(c->d_c1, shift + 2 * (size_t)off, sizeof(c128) * G, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(c->d_r1, psi + off, sizeof(double) * G, hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int) * G, c->st));
+        LuWs w = make_ws(c, n, G);
+        const double* dU = nullptr;
+        if (pert_mode == MAUS_PERT_UNIFORM) {
+            size_t ub = sizeof(double) * 2 * (size_t)n * n * G;
+            if (ub > c->Ubytes) { if (c->Upert) (void)hipFree(c->Upert); c->Upert = nullptr; HIPCHK(c, hipMalloc((void**)&c->Upert, ub)); c->Ubytes = ub; }
+            HIPCHK(c, hipMemcpyAsync(c->Upert, (const double*)pert_data + 2 * (size_t)n * n * off, ub, hipMemcpyHostToDevice, c->st));
+            dU = c->Upert;
+        }
+        if (pert_mode == MAUS_PERT_MT19937) {
+            if (mt_prepare_and_build(c, w, (const maus_mt_desc*)pert_data, off, G, rhs_mode, 0, 0)) return -1;
+        } else
+            maus_build_h(w, c->A, c->d_c1, c->d_r1, rhs_mode, c->X, c->ldp, c->d_slots, c->b, pert_mode, dU);
+        HIPCHK(c, hipMemcpyAsync(h_flags.data(), c->flags, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
+        if (maus_gmres_run(c, slots + off, G, shift + 2 * (size_t)off, psi + off, rhs_mode, want_jacobi + off, rtol, restart, maxiter,
+                           info_out + off, inner_out + off, status + off, w.H, w.ldh, w.strideH, jacobi_out ? jacobi_out + off : nullptr))
+            return -1;
+        for (int g = 0; g < G; ++g) if (h_flags[g] & 1) status[off + g] = -1;       // non-finite H_k / rhs (AMS:94 analogue)
+    }
+    return 0;
 }
 
 int maus_jacobi_check(maus_ctx* c, int count, const double* shift, const double* psi, int32_t* ok) {

@@ -36,7 +36,8 @@ void maus_launch_norm_scale(hipStream_t st, const c128* S, c128* D, long ld, con
 void maus_launch_norm(hipStream_t st, const c128* S, long ld, const int* slots, int count, int n, double* norm_out, int stride_out, int off_out);
 void maus_launch_herm_pick(hipStream_t st, const c128* S, long lds_, c128* X, long ldx, const int* slots, int count, const c128* V, int n, int* idx_out, double* norm_out);
 int maus_gmres_run(maus_ctx* ctx, const int* slots, int count, const double* shift, const double* psi, int rhs_mode,
-                   const int32_t* use_jacobi, double rtol, int restart, int maxiter, int32_t* info_out, int32_t* inner_out, int32_t* status);
+                   const int32_t* use_jacobi, double rtol, int restart, int maxiter, int32_t* info_out, int32_t* inner_out, int32_t* status,
+                   const c128* Hdense, long ldh, long strideH, int32_t* jacobi_out);
 int maus_jacobi_check_run(maus_ctx* ctx, int count, const double* shift, const double* psi, int32_t* ok);
 
 // ---- context ---------------------------------------------------------------------------
@@ -58,7 +59,7 @@ struct maus_ctx {
     double *d_r1 = nullptr, *d_r2 = nullptr;
     // LU workspace
     c128* H = nullptr; size_t Hbytes = 0; int Hg = 0; int Hnpad = 0; int ws_allocs = 0;
-    int *ipiv = nullptr, *info = nullptr, *flags = nullptr;
+    int *ipiv = nullptr, *perm = nullptr, *info = nullptr, *flags = nullptr;
     double* Upert = nullptr; size_t Ubytes = 0;
     // device-side MT19937 regeneration (mtdev.hip)
     // one buffer set per sub-batch stream: the host prepares sub-batch s+1 while the jump / build kernels of sub-batch s

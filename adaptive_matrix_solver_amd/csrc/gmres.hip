@@ -7,12 +7,19 @@
 // LAPACK zlartg convention, adaptive inner tolerance `ptol`, true-residual exit
 // ||b - H x|| <= rtol*||b||, info = maxiter when the restart cycles are exhausted.
 //
-// H_k = A - shift_k I + psi_k I is never materialised: every inner iteration of ALL active
-// candidates is ONE MFMA zgemm  Y = Z * A^T  (Z = the candidates' current Krylov vectors,
+// Shared-matrix mode (maus_gmres): H_k = A - shift_k I + psi_k I is never materialised: every inner iteration of ALL
+// active candidates is ONE MFMA zgemm  Y = Z * A^T  (Z = the candidates' current Krylov vectors,
 // gathered by row index) followed by a per-candidate kernel that adds (psi_k - shift_k) z,
 // applies the Jacobi scale, orthogonalises (MGS, wavefront reductions), and runs the small
 // Hessenberg / Givens / ptol state machine on one lane.  Each candidate advances through its
 // own (cycle, column) state; the host only launches "ticks" until no candidate is active.
+//
+// Dense mode (maus_gmres_pert): the reference's H_solve of the GMRES branch also carries the random term
+// 0.15 psi ((U1-.5) + i(U2-.5)) (AMS:49-52, 89).  At the default psi ~ 1e-19 that is below the rounding of one matvec
+// and the shared-matrix mode is used; once psi has been escalated (attempt / stuck / aggression factors) it is not,
+// and the candidates' H_k are materialised in the LU workspace (the same build kernels as the direct solve, i.e. the
+// same bits as the reference's H_solve) -- the matvec is then one HBM-bound GEMV per candidate against its own H_k,
+// and the Jacobi scale and its AMS:67-72 gate read diag(H_k) from the materialised matrix.
 #include "ctx.h"
 #include <algorithm>
 #include <cstring>
@@ -127,6 +134,7 @@ struct GArgs {
     const c128* dA; const c128* shift; const double* psi; const int* jac;
     const c128* X; long ldx; const int* slots; const c128* bvec; int rhs_mode;
     c128* Vb; c128* Y; GState* st;
+    const c128* Hd; long ldh, strideH;    // dense mode: materialised H_k (null in shared-matrix mode)
 };
 
 __device__ __forceinline__ const c128* rhs_of(const GArgs& a, int k) {
@@ -134,9 +142,59 @@ __device__ __forceinline__ const c128* rhs_of(const GArgs& a, int k) {
 }
 __device__ __forceinline__ c128 psolve1(const GArgs& a, int k, int i, c128 v) {
     if (!a.jac[k]) return v;
-    const c128 lam = a.shift[k];
-    const c128 d = cmake(__dadd_rn(__dsub_rn(a.dA[i].x, lam.x), a.psi[k]), __dadd_rn(__dsub_rn(a.dA[i].y, lam.y), 0.0));
+    c128 d;
+    if (a.Hd) d = a.Hd[(long)k * a.strideH + (long)i * a.ldh + i];
+    else {
+        const c128 lam = a.shift[k];
+        d = cmake(__dadd_rn(__dsub_rn(a.dA[i].x, lam.x), a.psi[k]), __dadd_rn(__dsub_rn(a.dA[i].y, lam.y), 0.0));
+    }
     return cmul(crecip_np(d), v);
+}
+
+// dense mode, AMS:65-86: Jacobi only where it was asked for AND every 1/diag(H_k) is finite and every |diag(H_k)| > 1e-12
+__global__ void __launch_bounds__(GT)
+jacobi_gate_dense_kernel(GArgs a, int* __restrict__ jac) {
+    __shared__ int sbad;
+    const int k = blockIdx.x;
+    if (threadIdx.x == 0) sbad = 0;
+    __syncthreads();
+    bool bad = false;
+    if (jac[k]) {
+        for (int i = threadIdx.x; i < a.n; i += GT) {
+            const c128 d = a.Hd[(long)k * a.strideH + (long)i * a.ldh + i];
+            const c128 inv = crecip_np(d);
+            if (!cfinite(inv) || !(hypot(d.x, d.y) > 1e-12)) bad = true;
+        }
+    }
+    if (bad) atomicOr(&sbad, 1);
+    __syncthreads();
+    if (threadIdx.x == 0 && sbad) jac[k] = 0;
+}
+
+// dense mode matvec: Y[k] = H_k z_k for the active candidates.  One wave per matrix row at a time (a row is n x 16
+// contiguous bytes), 16 rows per workgroup, z through L2: HBM-bound on H_k.
+__global__ void __launch_bounds__(GT)
+gemv_dense_kernel(GArgs a, const int* __restrict__ act, const int* __restrict__ zrow) {
+    const int k = act[blockIdx.y];
+    const c128* H = a.Hd + (long)k * a.strideH;
+    const c128* z = a.Vb + (long)zrow[blockIdx.y] * a.n;
+    c128* y = a.Y + (long)k * a.n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * 16 + wave * 4;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int i = r0 + rr;
+        if (i >= a.n) break;
+        const c128* row = H + (long)i * a.ldh;
+        double sr = 0.0, si = 0.0;
+        for (int j = lane; j < a.n; j += 64) {
+            const c128 h = row[j], v = z[j];
+            sr = fma(h.x, v.x, sr); sr = fma(-h.y, v.y, sr);
+            si = fma(h.x, v.y, si); si = fma(h.y, v.x, si);
+        }
+        sr = wave_sum(sr); si = wave_sum(si);
+        if (lane == 0) y[i] = cmake(sr, si);
+    }
 }
 
 // x0 = b; norms; ptol (iterative.py:696-724)
@@ -211,7 +269,8 @@ gmres_post_kernel(GArgs a, const int* __restrict__ act) {
     c128* x = Vk + (long)(R + 1) * n;
     const c128* y = a.Y + (long)k * n;
     const c128 lam = a.shift[k];
-    const c128 sh = cmake(a.psi[k] - lam.x, -lam.y);          // H z = A z + (psi - lambda) z
+    // H z = A z + (psi - lambda) z ; in dense mode the shift is part of the materialised H_k
+    const c128 sh = a.Hd ? cmake(0.0, 0.0) : cmake(a.psi[k] - lam.x, -lam.y);
     c128 w[EPT];
 
     if (phase == 1) {
@@ -419,7 +478,7 @@ int maus_jacobi_check_run(maus_ctx* c, int count, const double* shift, const dou
 
 int maus_gmres_run(maus_ctx* c, const int* slots, int count, const double* shift, const double* psi, int rhs_mode,
                    const int32_t* use_jacobi, double rtol, int restart, int maxiter, int32_t* info_out, int32_t* inner_out,
-                   int32_t* status) {
+                   int32_t* status, const c128* Hdense, long ldh, long strideH, int32_t* jacobi_out) {
     if (!c->A || !c->X) FAIL(c, "maus_gmres: matrix/population missing");
     if (c->rows != c->cols) FAIL(c, "maus_gmres: square matrix required");
     if (rhs_mode == 1 && (!c->b || c->bn != c->rows)) FAIL(c, "maus_gmres: rhs b not set");
@@ -443,11 +502,13 @@ int maus_gmres_run(maus_ctx* c, const int* slots, int count, const double* shift
     a.dA = (c128*)(base + o_d); a.Vb = (c128*)(base + o_v); a.Y = (c128*)(base + o_y); a.st = (GState*)(base + o_s);
     int* act = (int*)(base + o_a); int* zrow = (int*)(base + o_z); int* nact = (int*)(base + o_n);
     int* jac = (int*)(base + o_j); int* outs = (int*)(base + o_o);
+    a.Hd = Hdense; a.ldh = ldh; a.strideH = strideH;
     a.shift = c->d_c1; a.psi = c->d_r1; a.jac = jac; a.X = c->X; a.ldx = c->ldp; a.slots = c->d_slots; a.bvec = c->b; a.rhs_mode = rhs_mode;
     HIPCHK(c, hipMemcpyAsync(c->d_c1, shift, sizeof(c128) * count, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(c->d_r1, psi, sizeof(double) * count, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(jac, use_jacobi, sizeof(int) * count, hipMemcpyHostToDevice, c->st));
     hipLaunchKernelGGL(diag_kernel, dim3((n + 255) / 256), dim3(256), 0, c->st, c->A, n, (c128*)(base + o_d));
+    if (Hdense) hipLaunchKernelGGL(jacobi_gate_dense_kernel, dim3(count), dim3(GT), 0, c->st, a, jac);
     hipLaunchKernelGGL(gmres_init_kernel, dim3(count), dim3(GT), 0, c->st, a);
     const long max_ticks = (long)maxiter * (R + 1) + 2;
     int h_nact = 0;
@@ -456,6 +517,10 @@ int maus_gmres_run(maus_ctx* c, const int* slots, int count, const double* shift
         HIPCHK(c, hipMemcpyAsync(&h_nact, nact, sizeof(int), hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
         if (h_nact <= 0) break;
+        if (Hdense) {
+            ProfScope ps(c, KC_VEC, 0, 16.0 * h_nact * (double)n * n);
+            hipLaunchKernelGGL(gemv_dense_kernel, dim3((n + 15) / 16, h_nact), dim3(GT), 0, c->st, a, act, zrow);
+        } else
         { ProfScope ps(c, KC_GEMM, 8.0 * h_nact * (double)n * n, 16.0 * ((double)n * n + 2.0 * h_nact * n));
           maus_zgemm_launch_idx(c->st, h_nact, n, n, a.Vb, n, 0, c->A, n, 0, a.Y, n, 0, 1.0, 0, 1, 1, false, false, zrow, act); }
         { ProfScope ps(c, KC_VEC, 0, 16.0 * h_nact * (double)n * (R + 4));
@@ -467,6 +532,7 @@ int maus_gmres_run(maus_ctx* c, const int* slots, int count, const double* shift
     HIPCHK(c, hipMemcpyAsync(info_out, outs, sizeof(int) * count, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipMemcpyAsync(inner_out, outs + count, sizeof(int) * count, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipMemcpyAsync(status, outs + 2 * count, sizeof(int) * count, hipMemcpyDeviceToHost, c->st));
+    if (jacobi_out) HIPCHK(c, hipMemcpyAsync(jacobi_out, jac, sizeof(int) * count, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     HIPCHK(c, hipGetLastError());
     return 0;

@@ -29,6 +29,11 @@ void maus_zgemm_launch(hipStream_t st, int M, int N, int K, const c128* A, long 
                        const c128* B, long ldb, long sB, c128* C, long ldc, long sC,
                        double alpha, int beta, int batch, int blay, bool conja, bool conjb);
 
+void maus_zgemm_launch_rows(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,
+                            const c128* B, long ldb, long sB, c128* C, long ldc, long sC,
+                            double alpha, int beta, int batch, int blay, bool conja, bool conjb,
+                            const int* a_rows, const int* c_rows, long rows_stride);
+
 namespace {
 
 #ifndef MAUS_NBP
@@ -551,6 +556,229 @@ trsm32_kernel(c128* __restrict__ Hg, long ld, long strideH, int j, int c_lo, int
     for (int i = 1; i < TW; ++i) H[(long)(j + i) * ld + col] = x[i];
 }
 
+
+// =======================================================================================
+// Implicit pivoting (default).  Rows never move: perm[i] is the physical row of H holding logical row i, a row
+// interchange is a swap of two perm entries, and every kernel addresses rows through perm (the zgemm gathers its A / C
+// rows through the same list).  That removes the laswp sweeps altogether -- 600 MB of HBM traffic per matrix and
+// factorisation at n = 4096 (each outer block's 512 interchanges applied to everything to its right, plus the
+// interchanges inside the block column at every recursion level), 5 % of the step -- and the in-panel swaps of the
+// other 12 panel columns.  The pivot choice is unchanged: the search runs over LOGICAL row indices, first index wins,
+// so ipiv is LAPACK's sequence.  Finished U rows go to the second array U in logical order (written once, by the
+// triangular solves and the panel), which keeps the B operand of every update and the back substitution contiguous.
+// =======================================================================================
+__global__ void __launch_bounds__(256)
+init_perm_kernel(int* __restrict__ perm_g, int npad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npad) perm_g[(long)blockIdx.y * npad + i] = i;
+}
+
+// Left-looking base panel with implicit pivoting; structure and pivot rule of lu_panel_ll_kernel.
+template <int RPT, int PWL>
+__global__ void __launch_bounds__(PT)
+lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long strideH, int j0, int m,
+                   int* __restrict__ ipiv_g, int* __restrict__ perm_g, int npad, int* __restrict__ info_g)
+{
+    c128* Hm = Hg + (long)blockIdx.x * strideH + j0;                       // physical row 0, panel column 0
+    c128* Um = Ug + (long)blockIdx.x * strideH + (long)j0 * ld + j0;       // logical row j0, panel column 0
+    int* ipiv = ipiv_g + (long)blockIdx.x * npad + j0;
+    int* perm = perm_g + (long)blockIdx.x * npad + j0;                     // perm[r]: physical row of panel-local logical row r
+
+    constexpr int LW = NBP - PWL;                 // widest finished part (12 columns)
+    __shared__ c128 s_piv[PWL];
+    __shared__ c128 s_old[PWL];
+    __shared__ double s_val[PT / 64];
+    __shared__ int s_idx[PT / 64];
+    __shared__ c128 s_L00[LW][LW];
+    __shared__ c128 s_U[LW][PWL];
+    __shared__ int s_prow[NBP];                   // physical rows of the pivots chosen so far
+    __shared__ int s_pphys, s_aphys;
+    __shared__ int s_info;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_info = 0;
+    c128 R[RPT][PWL];
+    int pr[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) { const int r = tid + k * PT; pr[k] = (r < m) ? perm[r] : 0; }
+
+#pragma unroll
+    for (int sb = 0; sb < NBP / PWL; ++sb) {
+        const int c0 = sb * PWL;
+        if (sb > 0) {
+            // (b') U block of this sub-block's columns above the diagonal block (rows = the pivots chosen so far)
+            for (int e = tid; e < c0 * c0; e += PT) { const int j = e / c0, i = e - j * c0; s_L00[j][i] = Hm[(long)s_prow[j] * ld + i]; }
+            for (int e = tid; e < c0 * PWL; e += PT) { const int j = e / PWL, c = e - j * PWL; s_U[j][c] = Hm[(long)s_prow[j] * ld + c0 + c]; }
+            __syncthreads();
+            if (tid < PWL) {
+                for (int j = 1; j < c0; ++j) {
+                    c128 u = s_U[j][tid];
+                    for (int i = 0; i < j; ++i) cfms(u, s_L00[j][i], s_U[i][tid]);
+                    s_U[j][tid] = u;
+                }
+                for (int j = 0; j < c0; ++j) Um[(long)j * ld + c0 + tid] = s_U[j][tid];      // final U entries
+            }
+            __syncthreads();
+        }
+        // (c') load this thread's rows of the sub-block, bringing them up to date on the way (pivot rows are done)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = tid + k * PT;
+            if (r < m && r >= c0) {
+                const c128* row = Hm + (long)pr[k] * ld;
+                c128 nw[PWL];
+#pragma unroll
+                for (int c = 0; c < PWL; ++c) nw[c] = row[c0 + c];
+                if (sb > 0) {
+#pragma unroll
+                    for (int pb = 0; pb < LW / PWL; ++pb) {
+                        if (pb < sb) {
+                            c128 l[PWL];
+#pragma unroll
+                            for (int j = 0; j < PWL; ++j) l[j] = row[pb * PWL + j];
+#pragma unroll
+                            for (int j = 0; j < PWL; ++j)
+#pragma unroll
+                                for (int c = 0; c < PWL; ++c) cfms(nw[c], l[j], s_U[pb * PWL + j][c]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < PWL; ++c) R[k][c] = nw[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < PWL; ++c) {
+            const int a = c0 + c;            // pivot position (panel-local logical row == column index)
+            // ---- pivot search: max |re|+|im| over logical rows >= a, first index wins ----
+            double best = -1.0; int bidx = INT_MAX;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = tid + k * PT;
+                if (r < m && r >= a) {
+                    double v = cabs1(R[k][c]);
+                    if (v > best) { best = v; bidx = r; }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                double ov = __shfl_xor(best, o, 64);
+                int oi = __shfl_xor(bidx, o, 64);
+                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            }
+            if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
+            lds_barrier();
+            best = s_val[0]; bidx = s_idx[0];
+#pragma unroll
+            for (int w = 1; w < PT / 64; ++w) {
+                double ov = s_val[w]; int oi = s_idx[w];
+                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            }
+            const int p = (bidx == INT_MAX) ? a : bidx;   // all-NaN column: no interchange (input flagged non-finite)
+            // ---- publish pivot row / displaced row of the register sub-block and their physical rows ----
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = tid + k * PT;
+                if (r == p) {
+#pragma unroll
+                    for (int cc = 0; cc < PWL; ++cc) s_piv[cc] = R[k][cc];
+                    s_pphys = pr[k];
+                }
+                if (r == a && p != a) {
+#pragma unroll
+                    for (int cc = 0; cc < PWL; ++cc) s_old[cc] = R[k][cc];
+                    s_aphys = pr[k];
+                }
+            }
+            if (tid == 0) ipiv[a] = j0 + p;
+            lds_barrier();
+            // the interchange: two threads exchange the register rows AND the physical rows they stand for
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = tid + k * PT;
+                if (p != a) {
+                    if (r == a) {
+#pragma unroll
+                        for (int cc = 0; cc < PWL; ++cc) R[k][cc] = s_piv[cc];
+                        pr[k] = s_pphys;
+                    } else if (r == p) {
+#pragma unroll
+                        for (int cc = 0; cc < PWL; ++cc) R[k][cc] = s_old[cc];
+                        pr[k] = s_aphys;
+                    }
+                }
+            }
+            if (tid == 0) s_prow[a] = s_pphys;
+            // row a of U inside this sub-block (columns >= a); the columns of later sub-blocks follow in their (b')
+            if (tid < PWL && tid >= c) Um[(long)a * ld + c0 + tid] = s_piv[tid];
+            const c128 pv = s_piv[c];
+            const bool zero_piv = (pv.x == 0.0 && pv.y == 0.0);
+            if (zero_piv && tid == 0 && s_info == 0) s_info = j0 + a + 1;   // LAPACK info (1-based)
+            const c128 rinv = zero_piv ? cmake(1.0, 0.0) : crecip(pv);
+            c128 prow[PWL];
+#pragma unroll
+            for (int cc = 0; cc < PWL; ++cc) prow[cc] = s_piv[cc];
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = tid + k * PT;
+                if (r < m && r > a) {
+                    c128 l = cmul(R[k][c], rinv);
+                    R[k][c] = l;
+#pragma unroll
+                    for (int cc = c + 1; cc < PWL; ++cc) cfms(R[k][cc], l, prow[cc]);
+                }
+            }
+            lds_barrier();     // s_piv / s_val / s_pphys are rewritten by the next column
+        }
+        // store the factored sub-block (L below the pivots; the pivot rows' own entries are only read back by (b'))
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = tid + k * PT;
+            if (r < m && r >= c0) {
+                c128* row = Hm + (long)pr[k] * ld;
+#pragma unroll
+                for (int c = 0; c < PWL; ++c) row[c0 + c] = R[k][c];
+            }
+        }
+        __syncthreads();       // the next sub-block reads these columns from memory
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) { const int r = tid + k * PT; if (r < m) perm[r] = pr[k]; }
+    if (tid == 0 && s_info != 0 && info_g[blockIdx.x] == 0) info_g[blockIdx.x] = s_info;
+}
+
+// U[j..j+TW, cols] = L11^-1 * H[perm[j..j+TW), cols]: the pivot rows are gathered through perm and their finished U
+// rows written to the logical-order array.
+template <int TW>
+__global__ void __launch_bounds__(256)
+trsm_ip_kernel(const c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long strideH, const int* __restrict__ perm_g,
+               int npad, int j, int c_lo, int c_hi)
+{
+    __shared__ c128 sL[TW][TW + 1];
+    __shared__ int sp[TW];
+    const c128* H = Hg + (long)blockIdx.y * strideH;
+    c128* U = Ug + (long)blockIdx.y * strideH;
+    if (threadIdx.x < TW) sp[threadIdx.x] = perm_g[(long)blockIdx.y * npad + j + threadIdx.x];
+    __syncthreads();
+    for (int e = threadIdx.x; e < TW * TW; e += blockDim.x) {
+        int r = e / TW, c = e % TW;
+        sL[r][c] = H[(long)sp[r] * ld + j + c];
+    }
+    __syncthreads();
+    const int col = c_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c_hi) return;
+    c128 x[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) x[i] = H[(long)sp[i] * ld + col];
+#pragma unroll
+    for (int i = 1; i < TW; ++i)
+#pragma unroll
+        for (int q = 0; q < i; ++q) cfms(x[i], sL[i][q], x[q]);
+#pragma unroll
+    for (int i = 0; i < TW; ++i) U[(long)(j + i) * ld + col] = x[i];
+}
+
 // ---------------------------------------------------------------------------------------
 // Back substitution U x = y (y = augmented column npad).  One workgroup per matrix,
 // 32-row blocks from the bottom: dot products of the U row tails against x (LDS), then a
@@ -612,8 +840,11 @@ backsolve_kernel(const c128* __restrict__ Hg, long ld, long strideH, int n, int 
 
 static inline void prof(const LuWs& w, int klass, int phase, double flops = 0, double bytes = 0) { if (w.tick) w.tick(w.ud, klass, phase, flops, bytes); }
 
+static bool lu_implicit() { static const int v = [] { const char* e = getenv("MAUS_LU_IMPLICIT"); return e ? atoi(e) : 1; }(); return v != 0; }
+
 static void lu_gemm(const LuWs& w, int r0, int r1, int c0, int c1, int k0, int k1) {
-    // H[r0:r1, c0:c1] -= H[r0:r1, k0:k1] * H[k0:k1, c0:c1]
+    // H[r0:r1, c0:c1] -= H[r0:r1, k0:k1] * H[k0:k1, c0:c1]   (implicit pivoting: rows r0:r1 through perm, the
+    // k0:k1 rows of the right factor are finished U rows and come from the logical-order array)
     int M = r1 - r0, N = c1 - c0, K = k1 - k0;
     if (M <= 0 || N <= 0 || K <= 0) return;
     const int kc = (K >= 256) ? KC_GEMM : (K >= 128) ? KC_GEMM_K128 : (K >= 64) ? KC_GEMM_K64 : (K >= 32) ? KC_GEMM_K32 : KC_GEMM_K16;
@@ -622,6 +853,11 @@ static void lu_gemm(const LuWs& w, int r0, int r1, int c0, int c1, int k0, int k
     static FILE* trace = [] { const char* e = getenv("MAUS_LU_TRACE"); return e ? fopen(e, "a") : (FILE*)nullptr; }();
     if (trace) { fprintf(trace, "%d %d %d %d\n", M, N, K, w.G); fflush(trace); }
     prof(w, kc, 0);
+    if (lu_implicit())
+        maus_zgemm_launch_rows(w.st, M, N, K, w.H + k0, w.ldh, w.strideH,
+                               w.U + (long)k0 * w.ldh + c0, w.ldh, w.strideH,
+                               w.H + c0, w.ldh, w.strideH, -1.0, 1, w.G, 0, false, false, w.perm + r0, w.perm + r0, w.npad);
+    else
     maus_zgemm_launch(w.st, M, N, K, w.H + (long)r0 * w.ldh + k0, w.ldh, w.strideH,
                       w.H + (long)k0 * w.ldh + c0, w.ldh, w.strideH,
                       w.H + (long)r0 * w.ldh + c0, w.ldh, w.strideH, -1.0, 1, w.G, 0, false, false);
@@ -629,7 +865,7 @@ static void lu_gemm(const LuWs& w, int r0, int r1, int c0, int c1, int k0, int k
 }
 
 static void lu_laswp(const LuWs& w, int k1, int k2, int c_lo, int c_hi) {
-    if (c_hi <= c_lo || k2 <= k1) return;
+    if (c_hi <= c_lo || k2 <= k1 || lu_implicit()) return;
     prof(w, KC_LASWP, 0);
     dim3 grid((c_hi - c_lo + 255) / 256, w.G);
     hipLaunchKernelGGL(laswp_kernel, grid, dim3(256), 0, w.st, w.H, w.ldh, w.strideH, w.ipiv, w.npad, k1, k2, c_lo, c_hi);
@@ -643,7 +879,11 @@ static void lu_trsm(const LuWs& w, int j, int k, int c_lo, int c_hi) {
     if (k <= NBP || (tw32 && k == 32)) {
         prof(w, KC_TRSM, 0);
         dim3 grid((c_hi - c_lo + 255) / 256, w.G);
-        if (k == 32 && NBP < 32) hipLaunchKernelGGL((trsm32_kernel<32>), grid, dim3(256), 0, w.st, w.H, w.ldh, w.strideH, j, c_lo, c_hi);
+        if (lu_implicit()) {
+            if (k == 32 && NBP < 32) hipLaunchKernelGGL((trsm_ip_kernel<32>), grid, dim3(256), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+            else hipLaunchKernelGGL((trsm_ip_kernel<NBP>), grid, dim3(256), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+        }
+        else if (k == 32 && NBP < 32) hipLaunchKernelGGL((trsm32_kernel<32>), grid, dim3(256), 0, w.st, w.H, w.ldh, w.strideH, j, c_lo, c_hi);
         else hipLaunchKernelGGL((trsm32_kernel<NBP>), grid, dim3(256), 0, w.st, w.H, w.ldh, w.strideH, j, c_lo, c_hi);
         prof(w, KC_TRSM, 1, 4.0 * k * k * (c_hi - c_lo) * w.G, 32.0 * k * (c_hi - c_lo) * w.G);
         return;
@@ -663,13 +903,19 @@ static void lu_panel(const LuWs& w, int j0) {
     static const int ll = [] { const char* e = getenv("MAUS_PANEL_LL"); return e ? atoi(e) : 1; }();
 #define PANEL(R) hipLaunchKernelGGL((lu_panel_kernel<R>), grid, block, 0, w.st, w.H, w.ldh, w.strideH, j0, m, w.ipiv, w.npad, w.info, dbg)
 #define PANEL_LL(R, W) hipLaunchKernelGGL((lu_panel_ll_kernel<R, W>), grid, block, 0, w.st, w.H, w.ldh, w.strideH, j0, m, w.ipiv, w.npad, w.info)
-    if (ll || rpt > 8) {
+#define PANEL_IP(R, W) hipLaunchKernelGGL((lu_panel_ip_kernel<R, W>), grid, block, 0, w.st, w.H, w.U, w.ldh, w.strideH, j0, m, w.ipiv, w.perm, w.npad, w.info)
+    if (lu_implicit()) {
+        if (rpt <= 1) PANEL_IP(1, 4); else if (rpt <= 2) PANEL_IP(2, 4); else if (rpt <= 4) PANEL_IP(4, 4);
+        else if (rpt <= 8) PANEL_IP(8, 4); else PANEL_IP(16, 2);
+    }
+    else if (ll || rpt > 8) {
         if (rpt <= 1) PANEL_LL(1, 4); else if (rpt <= 2) PANEL_LL(2, 4); else if (rpt <= 4) PANEL_LL(4, 4);
         else if (rpt <= 8) PANEL_LL(8, 4); else PANEL_LL(16, 2);
     }
     else { if (rpt <= 1) PANEL(1); else if (rpt <= 2) PANEL(2); else if (rpt <= 4) PANEL(4); else PANEL(8); }
 #undef PANEL
 #undef PANEL_LL
+#undef PANEL_IP
     prof(w, KC_PANEL, 1, 8.0 * m * NBP * NBP / 2 * w.G, 16.0 * m * NBP * 8 * w.G);
 }
 
@@ -690,6 +936,7 @@ int maus_lu_max_npad() { return PT * 16; }     // 16 rows per thread in the 2-co
 // Factor all G matrices in the workspace and carry the augmented column through (L y = P b).
 void maus_lu_factor(const LuWs& w, int nbo) {
     const int ncols = (int)w.ldh;                 // npad + 32
+    if (lu_implicit()) hipLaunchKernelGGL(init_perm_kernel, dim3((w.npad + 255) / 256, w.G), dim3(256), 0, w.st, w.perm, w.npad);
     for (int J = 0; J < w.npad; J += nbo) {
         int wd = (w.npad - J < nbo) ? (w.npad - J) : nbo;
         lu_recurse(w, J, wd);
@@ -707,7 +954,7 @@ void maus_lu_backsolve(const LuWs& w, c128* Wpop, long ldw, const int* d_slots, 
         (void)hipFuncSetAttribute((const void*)backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(backsolve_kernel, dim3(w.G), dim3(1024), shm, w.st, w.H, w.ldh, w.strideH, w.n, w.npad,
+    hipLaunchKernelGGL(backsolve_kernel, dim3(w.G), dim3(1024), shm, w.st, lu_implicit() ? w.U : w.H, w.ldh, w.strideH, w.n, w.npad,
                        Wpop, ldw, d_slots, xout_dense, w.flags);
     prof(w, KC_BACKSOLVE, 1, 4.0 * w.npad * w.npad * w.G, 8.0 * w.npad * w.npad * w.G);
 }

@@ -34,7 +34,7 @@ zgemm_kernel(int M, int N, int K,
              const c128* __restrict__ Bg, long ldb, long strideB,
              c128* __restrict__ Cg, long ldc, long strideC,
              double alpha, int beta, int tiles_n, int nwg,
-             const int* __restrict__ a_rows, const int* __restrict__ c_rows)
+             const int* __restrict__ a_rows, const int* __restrict__ c_rows, long rows_stride)
 {
     constexpr int NT = 64 * WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
@@ -81,6 +81,10 @@ zgemm_kernel(int M, int N, int K,
     const c128* A = Ag + batch * strideA;
     const c128* B = Bg + batch * strideB;
     c128* C = Cg + batch * strideC;
+    // row gather (A) / scatter (C): one index list for every matrix (rows_stride = 0: population slots, Krylov rows) or
+    // one list per matrix (the LU's row permutation: implicit pivoting)
+    if (a_rows) a_rows += batch * rows_stride;
+    if (c_rows) c_rows += batch * rows_stride;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -296,13 +300,13 @@ zgemm_kernel(int M, int N, int K,
 template <int BM, int BN, int BK, int WM, int WN, bool PIPE, int MINW>
 void launch_cfg(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA, const c128* B, long ldb, long sB,
                 c128* C, long ldc, long sC, double alpha, int beta, int batch, int blay, bool conja, bool conjb,
-                const int* a_rows, const int* c_rows)
+                const int* a_rows, const int* c_rows, long rows_stride)
 {
     int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     int nwg = tiles_m * tiles_n;
     dim3 grid(nwg, batch), block(64 * WM * WN);
 #define LAUNCH(BL, CA, CB) hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WM, WN, BL, CA, CB, PIPE, MINW>), grid, block, 0, st, \
-        M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows)
+        M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows, rows_stride)
     if (blay == 0) {
         if (!conja && !conjb) LAUNCH(0, false, false);
         else if (!conja && conjb) LAUNCH(0, false, true);
@@ -321,12 +325,12 @@ void launch_cfg(hipStream_t st, int M, int N, int K, const c128* A, long lda, lo
 template <int BM, int BN, int BK, int WM, int WN, bool PIPE = false, int MINW = 4, bool M3 = false>
 void launch_lu_only(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA, const c128* B, long ldb, long sB,
                     c128* C, long ldc, long sC, double alpha, int beta, int batch, int, bool, bool,
-                    const int* a_rows, const int* c_rows)
+                    const int* a_rows, const int* c_rows, long rows_stride)
 {
     int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     int nwg = tiles_m * tiles_n;
     hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WM, WN, 0, false, false, PIPE, MINW, M3>), dim3(nwg, batch), dim3(64 * WM * WN), 0, st,
-                       M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows);
+                       M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows, rows_stride);
 }
 
 }  // namespace
@@ -334,15 +338,15 @@ void launch_lu_only(hipStream_t st, int M, int N, int K, const c128* A, long lda
 // Host-side launcher (device pointers).  batch matrices at element strides sA/sB/sC.
 // a_rows / c_rows (device int arrays of length M, or null): row gather for A / row scatter
 // for C -- the population's candidate vectors live in arbitrary slots of one array.
-void maus_zgemm_launch_idx(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,
-                           const c128* B, long ldb, long sB, c128* C, long ldc, long sC,
-                           double alpha, int beta, int batch, int blay, bool conja, bool conjb,
-                           const int* a_rows, const int* c_rows)
+void maus_zgemm_launch_rows(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,
+                            const c128* B, long ldb, long sB, c128* C, long ldc, long sC,
+                            double alpha, int beta, int batch, int blay, bool conja, bool conjb,
+                            const int* a_rows, const int* c_rows, long rows_stride)
 {
     if (M <= 0 || N <= 0 || batch <= 0) return;
     static const int cfg = [] { const char* e = getenv("MAUS_GEMM_CFG"); return e ? atoi(e) : 0; }();
     static const int use3m = [] { const char* e = getenv("MAUS_GEMM_3M"); return e ? atoi(e) : 1; }();
-#define ARGS st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, batch, blay, conja, conjb, a_rows, c_rows
+#define ARGS st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, batch, blay, conja, conjb, a_rows, c_rows, rows_stride
     // All kernels: 4 waves per workgroup and registers / LDS small enough for 3-4 INDEPENDENT workgroups per
     // CU.  Measured on MI355X (tools/gemm_cfg_check.py, gemm_sweep*.py; K=256, 136 matrices, 4M-equivalent
     // TFLOP/s): every one-workgroup-per-CU shape (128x64 / 128x128, BK 16/32, software-pipelined or not)
@@ -373,6 +377,14 @@ void maus_zgemm_launch_idx(hipStream_t st, int M, int N, int K, const c128* A, l
     // With the next K-tile genuinely in flight during the MFMAs this needs ~160 VGPRs: three workgroups per CU.
     launch_cfg<64, 64, 16, 2, 2, false, 3>(ARGS);
 #undef ARGS
+}
+
+void maus_zgemm_launch_idx(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,
+                           const c128* B, long ldb, long sB, c128* C, long ldc, long sC,
+                           double alpha, int beta, int batch, int blay, bool conja, bool conjb,
+                           const int* a_rows, const int* c_rows)
+{
+    maus_zgemm_launch_rows(st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, batch, blay, conja, conjb, a_rows, c_rows, 0);
 }
 
 void maus_zgemm_launch(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,

@@ -615,12 +615,19 @@ class DeviceEngine:
             e4 = None
             if nb > 0:
                 alpha = np.array([complex(c.alpha_local_step) for c in run[:nb]], dtype=np.complex128)
+                if is_eig and pert == PERT_MT19937:
+                    # device-side snapshot of the run's vectors (POP_U is unused by eig problems): an E4 event moves the
+                    # draws of everybody behind it, and their speculative update must then be undone
+                    self.ctx.pop_copy(POP_U, POP_X, [c._slot for c in run[:nb]])
                 nrm = self.d_relax(run[:nb], alpha, is_eig)
                 if is_eig:
                     tiny = np.nonzero(~(nrm > 1e-10))[0]
                     if tiny.size:
                         e4 = int(tiny[0])
-            nvalid = nb if (e4 is None or pert != PERT_UNIFORM) else e4 + 1
+            # E4 (AMS:283) consumes 2 x rand(N): with a stream-dependent perturbation (host draws or device-regenerated
+            # draws alike) the candidates behind it are recomputed from their new stream positions; with the perturbation
+            # dropped ('none') their results do not depend on the stream and are kept
+            nvalid = nb if (e4 is None or pert == PERT_NONE) else e4 + 1
             clean = ahead is not None and nvalid == len(run) and e4 is None and not fb.any()
             if ahead is not None and not clean:
                 ahead.discard()
@@ -647,6 +654,8 @@ class DeviceEngine:
             if pert == PERT_UNIFORM and nvalid < nb:
                 for c in run[nvalid:nb]:                                # speculative relax undone
                     c._restore_device()
+            if pert == PERT_MT19937 and nvalid < nb:
+                self.ctx.pop_copy(POP_X, POP_U, [c._slot for c in run[nvalid:nb]])
             i += nvalid
             if nvalid == nb and nb < len(run):
                 # --- the candidate whose first attempt failed: exact sequential ladder ---

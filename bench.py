@@ -323,7 +323,7 @@ def main():
                          "flops_per_launch_algorithmic": g["flops"] / max(1, g["launches"]),
                          "kernel_time_share": ((g["ms"] / tot_ms) if tot_ms > 0 else None) if args.kernel_events == "all" else None,
                          "measured_mfma_f64_issue_rate_tflops": 77.9,
-                         "lu_streams": int(os.environ.get("MAUS_LU_STREAMS", "2")),
+                         "lu_streams": int(os.environ.get("MAUS_LU_STREAMS", "3")),
                          "isolated_single_stream_pass": None if iso is None else {
                              "matrices": iso_active,
                              "achieved_algorithmic_8mnk": iso["zgemm"]["flops"] / max(1e-9, iso["zgemm"]["ms"] * 1e-3) / 1e12,

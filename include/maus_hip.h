@@ -85,6 +85,12 @@ int maus_pop_capacity(maus_ctx* ctx);
 int maus_pop_put(maus_ctx* ctx, int which, const int* slots, int count, const double* host_c128, int len);
 int maus_pop_get(maus_ctx* ctx, int which, const int* slots, int count, double* host_c128, int len);
 
+/* Device-side copy of the rows `slots` from population array which_src to which_dst (no host traffic).  Used to
+ * snapshot the candidates of a speculative batch before the relaxed update overwrites them, so that a run can be
+ * restarted behind an RNG event (E4 tiny-norm re-initialisation, AMS:283) exactly as the sequential reference
+ * would continue. */
+int maus_pop_copy(maus_ctx* ctx, int which_dst, int which_src, const int* slots, int count);
+
 /* ---- phases of update_solution_step, batched over `count` candidates ---- */
 /* Y[slot] = A @ X[slot]; num = vdot(v, A@v), den = vdot(v, v)      AMS:264-268.
  * num_c128: count complex; den_c128: count complex (imag is the rounded sum, ~0). */
@@ -150,13 +156,24 @@ int maus_gram(maus_ctx* ctx, int which, const int* slots, int count, int len, do
 
 /* Batched restarted GMRES with optional Jacobi preconditioner       AMS:60-90 ->
  * scipy/sparse/linalg/_isolve/iterative.py:692-841 (restart 20, MGS, Givens, ptol).
- *   H_k = A - shift_k I + psi_k I (MAUS_PERT_NONE only); x0 = rhs; W[slot] <- x
+ *   H_k = A - shift_k I + psi_k I (the random term of AMS:49-50 is left out: see maus_gmres_pert); x0 = rhs; W[slot] <- x
  * use_jacobi[count]: 1 -> M = diag(1/diag H_k) (caller applies AMS:65/72 gating via
  * maus_jacobi_check below).
  * info_out: 0 converged, maxiter otherwise (SciPy convention); inner_out: inner iterations. */
 int maus_gmres(maus_ctx* ctx, const int* slots, int count, const double* shift_c128, const double* psi,
                int rhs_mode, const int32_t* use_jacobi, double rtol, int restart, int maxiter,
                int32_t* info_out, int32_t* inner_out, int32_t* status);
+/* The same solver against the reference's FULL H_solve of the GMRES branch (AMS:49-52, 89):
+ *   H_k = A - shift_k I + psi_k I + 0.15 psi_k ((U1-.5) + i(U2-.5)),
+ * materialised per candidate in the LU workspace by the build kernels of maus_shifted_lu_solve (pert_mode / pert_data
+ * as there), matvec = one GEMV per candidate against its own H_k.  For escalated psi (retry ladder, large aggression /
+ * stuck factors) where the random term is no longer below the rounding of a matvec; maus_gmres is the fast path below
+ * that.  want_jacobi[count]: 1 -> use M = diag(1/diag H_k) provided the AMS:67-72 gate holds on diag(H_k) (evaluated on
+ * the device; jacobi_out[count], may be NULL, reports whether it was used).  status -1: non-finite H_k or rhs. */
+int maus_gmres_pert(maus_ctx* ctx, const int* slots, int count, const double* shift_c128, const double* psi,
+                    int rhs_mode, const int32_t* want_jacobi, int pert_mode, const void* pert_data,
+                    double rtol, int restart, int maxiter,
+                    int32_t* info_out, int32_t* inner_out, int32_t* status, int32_t* jacobi_out);
 /* AMS:67-72 gate: ok[i]=1 iff all 1/diag(H_k) finite and all |diag(H_k)| > 1e-12 */
 int maus_jacobi_check(maus_ctx* ctx, int count, const double* shift_c128, const double* psi, int32_t* ok);
 

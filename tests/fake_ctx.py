@@ -59,6 +59,10 @@ class FakeContext:
         for k, s in enumerate(slots):
             self.pop[which][s, : v.shape[1]] = v[k]
 
+    def pop_copy(self, which_dst, which_src, slots):
+        for s in slots:
+            self.pop[which_dst][s] = self.pop[which_src][s]
+
     def pop_get(self, which, slots, length):
         return np.array([self.pop[which][s, :length] for s in slots], dtype=np.complex128).reshape(len(slots), length)
 

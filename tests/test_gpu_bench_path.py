@@ -1,0 +1,329 @@
+"""Parity of the code path bench.py actually times (GPU box only).
+
+A batch of >= 64 solves runs as two sub-batches on two HIP streams (offsets into H, ipiv, info, flags, slots,
+shifts and generator states), and a batch beyond the LU workspace runs in chunks.  These tests compare THAT path --
+not a smaller single-stream one -- with independent references: host GEMM round trips and SciPy/LAPACK at the
+metric's size (n = 4096, 256 solves), NumPy for chunked batches, and the CPU oracle for whole loop bodies with
+>= 64 active candidates in the default perturbation mode (device-regenerated MT19937 draws), long enough for
+convergence, redundancy retirement, population growth past the workspace and converged-base spawns to occur.
+BASELINE.json's configs[1] (P = 256) and configs[2] (P = 512, as SURVEY §8d states it) run at full population.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import scenarios
+from oracle import maus_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _blas_threads():
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        yield
+        return
+    with threadpool_limits(limits=16):
+        yield
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from adaptive_matrix_solver_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+# ---------------------------------------------------------------------------------------------
+# the metric's configuration through the two-stream path: n = 4096, all 256 solves of a step at once
+# ---------------------------------------------------------------------------------------------
+def test_eig4096_pop256_two_streams_against_host_and_lapack(ctx):
+    import scipy.linalg as sla
+    from adaptive_matrix_solver_amd._cabi import PERT_MT19937
+    n, P = 4096, 256
+    A = scenarios.ginibre(n, 4096, None)
+    rng = np.random.default_rng(256)
+    V = (rng.standard_normal((P, n)) + 1j * rng.standard_normal((P, n))) / np.sqrt(n)
+    slots = list(range(P))
+    ctx.set_matrix(A)
+    ctx.pop_reserve(P)
+    ctx.pop_put(0, slots, V)
+    num, den = ctx.matvec_rayleigh(slots)
+    lam = num / den
+    psi = 1e-20 * 10.0 ** (np.arange(P) % 4 / 3.0)              # stuck counters 0..3 (AMS:44)
+    np.random.seed(4096)
+    st = np.random.get_state()
+    desc = (st, 4 * n * n, 0, np.arange(P, dtype=np.int32))
+    assert "MAUS_LU_STREAMS" not in os.environ                   # default: two sub-batch streams, as bench.py runs
+    status = ctx.shifted_lu_solve(slots, lam, psi, 0, PERT_MT19937, desc)
+    assert (status == 0).all()
+    W = ctx.pop_get(2, slots, n)
+    # (i) round trip H_k w_k = v_k for every candidate of both sub-batches (host GEMM)
+    HW = W @ A.T - (lam - psi)[:, None] * W
+    rel = np.linalg.norm(HW - V, axis=1) / np.linalg.norm(V, axis=1)
+    bound = 1e-13 * np.linalg.norm(A, 1) * np.linalg.norm(W, axis=1) / np.linalg.norm(V, axis=1)
+    assert (rel <= np.maximum(bound, 1e-12)).all(), (int(np.argmax(rel / np.maximum(bound, 1e-12))), rel.max())
+    # (ii) one stream instead of two: same bits for all 256 (the sub-batch offsets address the right matrices)
+    with _env(MAUS_LU_STREAMS=1):
+        status1 = ctx.shifted_lu_solve(slots, lam, psi, 0, PERT_MT19937, desc)
+        W1 = ctx.pop_get(2, slots, n)
+    assert (status1 == 0).all()
+    assert np.array_equal(W, W1), np.argwhere(np.any(W != W1, axis=1)).ravel()[:8]
+    # (iii) picked candidates (first / last of each sub-batch, one in the middle) against LAPACK: same pivot
+    # sequence (through the single-matrix entry point, whose solution must equal the batched one bit for bit) and
+    # the same solution to conditioning
+    for k in (0, 127, 128, 200, 255):
+        Hk = A - (lam[k] - psi[k]) * np.eye(n)
+        lu, piv = sla.lu_factor(Hk)
+        ref = sla.lu_solve((lu, piv), V[k])
+        x1, s1, ipiv = ctx.lu_solve(Hk, V[k], want_ipiv=True)
+        assert s1[0] == 0 and np.array_equal(ipiv[0], piv), k
+        assert np.linalg.norm(W[k] - ref) <= 1e-9 * np.linalg.norm(ref), (k, np.linalg.norm(W[k] - ref) / np.linalg.norm(ref))
+        # the 0.15*psi perturbation (1e-21) is below half an ulp of most entries but not of all of them: compare to
+        # rounding, not bit for bit
+        assert np.linalg.norm(W[k] - x1[0]) <= 1e-11 * np.linalg.norm(ref), k
+
+
+@pytest.mark.parametrize("n,count,cap", [(512, 200, 96), (160, 333, 128)])
+def test_chunked_batches_beyond_the_workspace(n, count, cap):
+    """count > workspace capacity: balanced chunks, each on two streams; against numpy.linalg.solve."""
+    from adaptive_matrix_solver_amd import Context
+    from adaptive_matrix_solver_amd._cabi import PERT_NONE
+    rng = np.random.default_rng(n + count)
+    A = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) / np.sqrt(n)
+    V = rng.standard_normal((count, n)) + 1j * rng.standard_normal((count, n))
+    lam = (rng.standard_normal(count) + 1j * rng.standard_normal(count)) * 0.5
+    psi = np.full(count, 1e-20)
+    slots = list(rng.permutation(count + 40)[:count])            # arbitrary (non-contiguous) slots
+    with _env(MAUS_LU_BATCH=cap):
+        c = Context(0)
+        try:
+            c.set_matrix(A)
+            c.pop_reserve(count + 40)
+            c.pop_put(0, slots, V)
+            assert c.lu_reserve(n, count) == cap
+            status = c.shifted_lu_solve(slots, lam, psi, 0, PERT_NONE, None)
+            W = c.pop_get(2, slots, n)
+            allocs = c.lu_workspace_allocations()
+            c.shifted_lu_solve(slots[:50], lam[:50], psi[:50], 0, PERT_NONE, None)
+            assert c.lu_workspace_allocations() == allocs        # no re-allocation for a smaller batch
+        finally:
+            c.close()
+    assert (status == 0).all()
+    for k in range(count):
+        Hk = A - (lam[k] - psi[k]) * np.eye(n)
+        ref = np.linalg.solve(Hk, V[k])
+        assert np.linalg.norm(W[k] - ref) <= 1e-10 * np.linalg.norm(ref) * max(1.0, np.linalg.cond(Hk) * 1e-4), k
+
+
+def test_status_codes_land_on_the_right_candidate_across_sub_batches(ctx):
+    """An exactly singular H_k (zero pivot -> LAPACK info) and a non-finite right-hand side planted at chosen
+    positions of a 150-solve batch: the per-candidate status must come back at those positions only."""
+    from adaptive_matrix_solver_amd._cabi import PERT_NONE
+    n, count = 64, 150
+    A = np.diag(np.arange(1.0, n + 1)).astype(np.complex128)     # eigenvalues 1..n: shift = k makes column k-1 zero
+    rng = np.random.default_rng(3)
+    V = rng.standard_normal((count, n)) + 1j * rng.standard_normal((count, n))
+    V[140, 5] = np.nan
+    lam = np.full(count, 0.5 + 0.25j)
+    lam[3], lam[77], lam[149] = 7.0, 20.0, 64.0
+    ctx.set_matrix(A)
+    ctx.pop_reserve(count)
+    ctx.pop_put(0, list(range(count)), V)
+    status = ctx.shifted_lu_solve(list(range(count)), lam, np.zeros(count), 0, PERT_NONE, None)
+    expect = np.zeros(count, dtype=np.int32)
+    expect[3], expect[77], expect[149], expect[140] = 7, 20, 64, -1
+    assert np.array_equal(status, expect), np.nonzero(status != expect)[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# whole loop bodies with >= 64 active candidates against the oracle
+# ---------------------------------------------------------------------------------------------
+LONG = {
+    # n > 256: the default perturbation mode is the bench's (device-regenerated draws); 64 -> ~260 active candidates,
+    # convergence from iteration ~9, ~40 redundancy retirements
+    "eig288_p64": (dict(kind="eig", build=("ginibre", 288, 300, None), P=64, iters=16, seed=11, tol=1e-8), {}),
+    # loose tolerance: landscape energy falls below 0.8 while solutions are converged -> converged-base spawns
+    # (AMS:539-547: random.choice, two random(), two rand(N) per spawn)
+    "eig96_loose": (dict(kind="eig", build=("ginibre", 96, 96, None), P=80, iters=10, seed=5, tol=0.3), dict(pert_mode="mt19937")),
+    # small structured problem run long: 96 -> 540 active candidates (beyond the 512-matrix workspace: chunks),
+    # convergence and redundancy retirement from iteration ~32
+    "lap8_p96": (dict(kind="eig", build=("laplace", 8, 8, False), P=96, iters=66, seed=7, tol=1e-7), dict(pert_mode="mt19937")),
+}
+
+
+def _active_view(rec):
+    """The iteration record restricted to the candidates that are still being stepped."""
+    act = [r for r in rec["rows"] if r["state"] not in (orc.CONVERGED, orc.RETIRED)]
+    ids = {r["id"] for r in act}
+    return dict(rec, rows=act, after=[i for i in rec["after"] if i in ids])
+
+
+def _converged_survivors(rec):
+    lam = {r["id"]: r["lam"] for r in rec["rows"] if r["state"] == orc.CONVERGED}
+    return [lam[i] for i in rec["after"] if i in lam]
+
+
+def compare_long(ref, got, anorm, name):
+    """Strict comparison (test_gpu_step_parity.compare: ids in list order, integer bookkeeping, both RNG streams, numerics)
+    up to the first iteration with two converged candidates; from there on the same strict comparison for every candidate
+    that is still stepped, and the converged survivors compared as a multiset of eigenvalues.  Reason (SURVEY §7,
+    tie-sensitivity): AMS:506 sorts by (-w_k, residual_k); converged candidates all have w_k = 1 and residuals that are
+    rounding noise of ||A v - lambda v|| (1e-13 here), so their relative order -- and with it WHICH of two duplicates of
+    an eigenpair is retired as redundant (AMS:509-520) -- is decided by bits that LAPACK's blocking and ours do not
+    share.  Converged candidates are never stepped again and the RNG consumption of a loop body does not depend on
+    their order, so everything else must still agree exactly."""
+    import test_gpu_step_parity as sp
+    nconv = [sum(1 for r in it["rows"] if r["state"] == orc.CONVERGED) for it in ref]
+    strict = next((k for k, c in enumerate(nconv) if c >= 2), len(ref))
+    sp.compare(ref[:strict], got[:strict], anorm, name)
+    sp.compare([_active_view(r) for r in ref], [_active_view(g) for g in got], anorm, name + "-active")
+    for it, (r, g) in enumerate(zip(ref, got)):
+        a, b = _converged_survivors(r), _converged_survivors(g)
+        assert len(a) == len(b), f"{name} iter {it}: {len(a)} vs {len(b)} converged survivors"
+        left = list(b)
+        for lam in a:
+            j = min(range(len(left)), key=lambda q: abs(left[q] - lam))
+            assert abs(left[j] - lam) <= 1e-8 * max(1.0, abs(lam)), f"{name} iter {it}: converged eigenvalue {lam} unmatched"
+            left.pop(j)
+    return strict
+
+
+@pytest.mark.parametrize("name", list(LONG))
+def test_long_trajectory_many_active_candidates(name):
+    import test_gpu_step_parity as sp
+    from threadpoolctl import threadpool_limits
+    spec, kw = LONG[name]
+    scenarios.TRAJECTORIES[name] = spec
+    try:
+        with threadpool_limits(limits=2):                   # small matrices: BLAS threads only fight each other
+            ref, anorm = sp.oracle_run(name, spec["iters"])
+        got = sp.product_run(name, spec["iters"], **kw)
+        compare_long(ref, got, anorm, name)
+        active = [sum(1 for r in it["rows"] if r["state"] not in (orc.CONVERGED, orc.RETIRED)) for it in ref]
+        assert min(active[:-1]) >= 64
+        assert any(r["state"] == orc.CONVERGED for it in ref for r in it["rows"])
+    finally:
+        scenarios.TRAJECTORIES.pop(name, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# configs[1] at its full population: 1024 x 1024, 256 candidates, whole loop bodies against the oracle
+# ---------------------------------------------------------------------------------------------
+def test_eig1024_pop256_against_oracle():
+    import test_gpu_step_parity as sp
+    scenarios.TRAJECTORIES["eig1024p256"] = dict(kind="eig", build=("ginibre", 1024, 1024, None), P=256, iters=2, seed=4321, tol=1e-8)
+    try:
+        ref, anorm = sp.oracle_run("eig1024p256", 2)
+        got = sp.product_run("eig1024p256", 2)
+        sp.compare(ref, got, anorm, "eig1024p256")
+    finally:
+        scenarios.TRAJECTORIES.pop("eig1024p256", None)
+
+
+# ---------------------------------------------------------------------------------------------
+# configs[2] as SURVEY §8d states it: 4096 x 4096 linear system, diag 10^U(0,7) e^{2 pi i U} + 0.1 Ginibre/sqrt(n)
+# (cond ~ 1e7 -> 'Fragile' -> GMRES preferred), 512 candidates, through MAUS_Solver.loop_body
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c3():
+    from adaptive_matrix_solver_amd.solver import MAUS_Solver, ProblemType, SolutionCandidate
+    n, P = 4096, 512
+    A, b = scenarios.wide_diag_system(n, 4096, decades=7.0, offdiag=0.1)
+
+    def make(seed):
+        np.random.seed(seed)
+        random.seed(seed)
+        SolutionCandidate._candidate_id_counter = 0
+        return MAUS_Solver(A, ProblemType.SOLVE_LINEAR_SYSTEM, b_vector=b, initial_num_candidates=P,
+                           global_convergence_tol=1e-8, quiet=True, record_history=False,
+                           diag_info=make.diag)
+    make.diag = None
+    s = make(1234)
+    make.diag = dict(s.diag_info)                                # the second sub-run reuses the (exact, ~20 s) cond
+    return n, P, A, b, make, s
+
+
+def _oracle_linear_candidates(A, b, n, seed, P, k, stuck):
+    """The oracle's first k candidates of a P-candidate linear population after one step (list order = RNG order,
+    so the first k are a prefix of the stream the device batch consumes)."""
+    orc.seed_all(seed)
+    pop = orc.new_population(A, orc.SOLVE_LINEAR_SYSTEM, b=b, n_cands=P, tol=1e-8)
+    orc.update_diagnostics(pop)
+    orc.adjust_strategy(pop)
+    out = []
+    for c in pop.cands[:k]:
+        c.stuck = stuck
+        orc.candidate_step(c, pop.M, pop.b, pop.strat, pop.know, gmres_mode="rtol")
+        out.append(c)
+    return pop, out
+
+
+@pytest.mark.parametrize("stuck", [0, 2])
+def test_lin4096_pop512_loop_body(c3, stuck):
+    from adaptive_matrix_solver_amd._cabi import mt19937_jump
+    n, P, A, b, make, first = c3
+    solver = first if stuck == 0 else make(1234)
+    assert solver.problem_knowledge["numerical_stability_state"] == "Fragile"
+    assert solver.problem_knowledge["local_solver_preference"] == "iterative_gmres"
+    S = type(solver.candidates[0]).State
+    for c in solver.candidates:
+        c.stuck_counter = stuck
+    X0 = np.array([np.asarray(c.x_k) for c in solver.candidates])
+    alpha0 = np.array([complex(c.alpha_local_step) for c in solver.candidates])
+    st0 = np.random.get_state()
+    solver._update_global_diagnostics(1)
+    solver._adjust_global_strategy(1)
+    assert solver.step_population() == P
+    cands = solver.candidates
+    X1 = np.array([np.asarray(c.x_k) for c in cands])
+    # bookkeeping (AMS:278, 286, 306-316): first attempt of the ladder succeeded for everybody
+    assert all(c.local_psi_retries_needed == 0 and c.num_resets == 0 for c in cands)
+    assert all(c.stuck_counter == max(0, stuck - 1) for c in cands)
+    assert all(c.state == S.REFINING for c in cands)
+    # stream position: stuck = 0 -> unpreconditioned GMRES exhausts 50 x 20 iterations, the direct-solver retry draws a
+    # second rand(N,N) pair (AMS:99-103): 8 N^2 words per candidate; stuck = 2 -> Jacobi, GMRES converges: 4 N^2
+    words = (8 if stuck == 0 else 4) * n * n * P
+    key, pos = mt19937_jump(st0[1], st0[2], words)
+    st1 = np.random.get_state()
+    assert st1[2] == pos and np.array_equal(st1[1], key)
+    # the solver result of every candidate, recovered from the relaxed update x1 = (1-a) x0 + a w (AMS:285),
+    # solves the (psi-regularised) system: residual at the level of the method used
+    W = (X1 - (1.0 - alpha0)[:, None] * X0) / alpha0[:, None]
+    R = W @ A.T - b[None, :]
+    rel = np.linalg.norm(R, axis=1) / np.linalg.norm(b)
+    assert (rel <= (1e-9 if stuck == 0 else 1.01e-8)).all(), rel.max()
+    # reported residuals are those of the updated iterates (AMS:299)
+    res_h = np.linalg.norm(X1 @ A.T - b[None, :], axis=1)
+    res_d = np.array([c.residual_k for c in cands])
+    assert np.allclose(res_d, res_h, rtol=1e-8)
+    # the first candidates against the oracle's restatement of the reference step (GMRES through tol -> rtol)
+    k = 1 if stuck == 0 else 3
+    pop, ref = _oracle_linear_candidates(A, b, n, 1234, P, k, stuck)
+    assert pop.know["local_solver_preference"] == orc.GMRES
+    for c, r in zip(cands[:k], ref):
+        assert (c.id, c.state.value, c.stuck_counter, c.local_psi_retries_needed) == (r.cid, r.state, r.stuck, r.retries)
+        assert np.linalg.norm(np.asarray(c.x_k) - r.x) <= 1e-7 * np.linalg.norm(r.x)
+        assert abs(c.residual_k - r.resid) <= 1e-6 * r.resid

@@ -22,6 +22,7 @@ TOL_LAMBDA = 1e-9        # |dlam| <= TOL * max(1, |lam|)
 TOL_RESID = 1e-6         # |dr|  <= TOL * max(r, 1e-9 * ||A||)   (abs floor for converged residuals)
 TOL_VEC = 1e-7           # 1 - |<v_gpu, v_ref>| / (|v||v|)  and  | |v| - |v_ref| | / |v_ref|
 TOL_ALPHA = 1e-12
+PHASE_FREE_BELOW = 1e-7   # residual / ||A||_1 under which the eigenvector's phase is rounding noise (see compare)
 
 
 def oracle_run(name, iters, gmres_mode="scipy-legacy"):
@@ -139,8 +140,12 @@ def compare(ref, got, anorm, name, vec_iters=None, tie_tol=None):
                     nr, ng = np.linalg.norm(vr), np.linalg.norm(vg)
                     assert abs(nr - ng) <= TOL_VEC * max(nr, 1e-300), ctag
                     assert 1.0 - abs(np.vdot(vr, vg)) / (nr * ng) <= TOL_VEC, ctag
-                    # same phase too (the update is linear in v, no sign freedom)
-                    assert np.linalg.norm(vr - vg) <= 1e-6 * nr, ctag
+                    # same phase too (the update is linear in v, no sign freedom) -- except where the Rayleigh shift
+                    # of this step sat within rounding of an eigenvalue (residual at convergence level): w is then
+                    # ~ x_i / (lambda_i - s) with lambda_i - s pure rounding noise, so its phase is decided by the last
+                    # bits of the factorisation (LAPACK's blocking vs ours); the direction is not
+                    if xr["resid"] > PHASE_FREE_BELOW * anorm:
+                        assert np.linalg.norm(vr - vg) <= 1e-6 * nr, ctag
 
 
 @pytest.mark.parametrize("name,iters", [("eig16", 10), ("eig64", 10), ("eig48u", 12)])

@@ -10,6 +10,7 @@
 #include "../adaptive_matrix_solver_amd/csrc/zgemm.hip"
 #include <cstdio>
 #include <vector>
+#include <chrono>
 
 template <int NREG>
 __device__ __forceinline__ void rmw(double2* __restrict__ p, size_t n, size_t stride_elems) {
@@ -65,26 +66,33 @@ int main(int argc, char** argv) {
     float tg = 0;
     { hipEventRecord(g0, sg); gemm(sg); gemm(sg); hipEventRecord(g1, sg); hipEventSynchronize(g1); hipEventElapsedTime(&tg, g0, g1); }
     printf("zgemm %dx%dx%d batch %d, two launches alone: %.2f ms (%.1f TFLOP/s algorithmic)\n", M, N, K, G, tg, 2 * 8.0 * M * N * K * G / (tg * 1e-3) / 1e12);
-    for (int wgs_per_cu : {2, 8}) for (auto& v : vars) {
-        const int grid = 256 * wgs_per_cu;
-        for (size_t frac = 1; frac <= 2; ++frac) {
-            const size_t n = nmem / (frac == 1 ? 4 : 2);                        // 8 / 16 GiB of traffic
-            float tm = 0, tb_g = 0, tb_m = 0, tall = 0, t_m_start = 0;
-            hipEventRecord(m0, sm); hipLaunchKernelGGL(v.k, dim3(grid), dim3(v.threads), 0, sm, mem, n); hipEventRecord(m1, sm);
-            hipEventSynchronize(m1); hipEventElapsedTime(&tm, m0, m1);
-            CK(hipDeviceSynchronize());
-            hipEventRecord(o, sg); hipStreamWaitEvent(sm, o, 0);
-            hipEventRecord(g0, sg); gemm(sg); gemm(sg); hipEventRecord(g1, sg);
-            hipEventRecord(m0, sm); hipLaunchKernelGGL(v.k, dim3(grid), dim3(v.threads), 0, sm, mem, n); hipEventRecord(m1, sm);
-            CK(hipDeviceSynchronize());
-            hipEventElapsedTime(&tb_g, g0, g1); hipEventElapsedTime(&tb_m, m0, m1);
-            float e_g = 0, e_m = 0; hipEventElapsedTime(&e_g, o, g1); hipEventElapsedTime(&e_m, o, m1); hipEventElapsedTime(&t_m_start, o, m0);
-            tall = e_g > e_m ? e_g : e_m;
-            const double bytes = 32.0 * n;
-            printf("%-8s grid %4d  %5.1f GB: alone %.2f ms (%.2f TB/s) | together: gemm %.2f ms, mem %.2f ms (ends at %.2f), wall %.2f ms | hidden %.0f %% of the shorter\n",
-                   v.name, grid, bytes / 1e9, tm, bytes / (tm * 1e-3) / 1e12, tb_g, tb_m, e_m, tall,
-                   100.0 * (tg + tm - tall) / (tm < tg ? tm : tg));
-        }
+    // The co-runner is launched ~25 ms AFTER the first of two back-to-back GEMM launches (the chip is saturated with zgemm
+    // workgroups by then), as `pieces` consecutive launches that together stream 4 x 32 GiB.
+    for (int grid : {256, 512, 1024}) for (int pieces : {1, 16}) for (auto& v : vars) {
+        if (v.threads == 512) continue;          // half- and whole-CU workgroups only start once the zgemm grid has drained (first version of this probe)
+        const size_t n = nmem;
+        const int reps = 3;
+        float tm = 0, tb_g = 0, tb_m = 0, e_g = 0, e_m = 0, t_m_start = 0;
+        auto mem_work = [&]() {
+            for (int r = 0; r < reps; ++r)
+                for (int pc = 0; pc < pieces; ++pc)
+                    hipLaunchKernelGGL(v.k, dim3(grid), dim3(v.threads), 0, sm, mem + (n / pieces) * pc, n / pieces);
+        };
+        hipEventRecord(m0, sm); mem_work(); hipEventRecord(m1, sm);
+        hipEventSynchronize(m1); hipEventElapsedTime(&tm, m0, m1);
+        CK(hipDeviceSynchronize());
+        hipEventRecord(o, sg);
+        hipEventRecord(g0, sg); gemm(sg); gemm(sg); hipEventRecord(g1, sg);
+        { auto t0 = std::chrono::steady_clock::now(); while (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < 25.0) {} }
+        hipEventRecord(m0, sm); mem_work(); hipEventRecord(m1, sm);
+        CK(hipDeviceSynchronize());
+        hipEventElapsedTime(&tb_g, g0, g1); hipEventElapsedTime(&tb_m, m0, m1);
+        hipEventElapsedTime(&e_g, o, g1); hipEventElapsedTime(&e_m, o, m1); hipEventElapsedTime(&t_m_start, o, m0);
+        const float wall = e_g > e_m ? e_g : e_m;
+        const double bytes = 32.0 * n * reps;
+        printf("%-8s grid %4d x%2d launches/rep %6.1f GB: alone %.2f ms (%.2f TB/s) | launched at %.1f ms into the gemm pair: gemm %.2f ms (alone %.2f), mem took %.2f ms (ends at %.1f), wall %.2f | hidden %.0f %% of the co-runner\n",
+               v.name, grid, pieces, bytes / 1e9, tm, bytes / (tm * 1e-3) / 1e12, t_m_start, tb_g, tg, tb_m, e_m, wall,
+               100.0 * (tg + tm - wall) / tm);
     }
     return 0;
 }
