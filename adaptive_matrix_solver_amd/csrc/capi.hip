@@ -11,6 +11,8 @@
 
 thread_local std::string g_err;
 
+static void hist_free(maus_ctx* c);
+
 int ensure_scalars(maus_ctx* c, int count) {
     if (count <= c->scal_cap) return 0;
     int cap = std::max(count, 2 * c->scal_cap);
@@ -113,6 +115,7 @@ int maus_ctx_destroy(maus_ctx* c) {
     void* ptrs[] = {c->A, c->b, c->V, c->X, c->U, c->W, c->Y, c->d_slots, c->d_i1, c->d_i2, c->d_c1, c->d_c2, c->d_r1, c->d_r2,
                     c->H, c->ipiv, c->perm, c->info, c->flags, c->Upert, c->scratch};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    hist_free(c);
     for (auto& kv : c->mt_taps) if (kv.second.first) (void)hipFree(kv.second.first);
     for (auto& b : c->mt_bufs) { if (b.states) (void)hipFree(b.states); if (b.ints) (void)hipFree(b.ints); if (b.base) (void)hipFree(b.base); }
     for (auto& r : c->pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -156,7 +159,7 @@ int maus_set_matrix(maus_ctx* c, const double* a, int rows, int cols) {
     HIPCHK(c, hipStreamSynchronize(c->st));
     if (rows != c->rows || cols != c->cols) {
         if (c->A) { (void)hipFree(c->A); c->A = nullptr; }
-        if (std::max(rows, cols) != c->ldp) free_population(c);      // vector length changed
+        if (std::max(rows, cols) != c->ldp) { free_population(c); hist_free(c); }      // vector length changed
         if (c->V) { (void)hipFree(c->V); c->V = nullptr; c->vn = 0; }
         HIPCHK(c, hipMalloc((void**)&c->A, sizeof(c128) * (size_t)rows * cols));
         c->rows = rows; c->cols = cols;
@@ -254,6 +257,83 @@ int maus_pop_copy(maus_ctx* c, int which_dst, int which_src, const int* slots, i
     if (count == 0) return 0;
     if (upload_slots(c, slots, count)) return -1;
     hipLaunchKernelGGL(copy_rows_kernel, dim3(count), dim3(256), 0, c->st, D, S, c->ldp, c->d_slots, (int)c->ldp);
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
+// ---- history store (AMS:126, 303-304: param_history keeps every iterate of every candidate) -------------------------
+// Rows are appended device-to-device (no PCIe traffic in the step) into fixed chunks that are never moved; a row is
+// addressed by its append index.  Beyond MAUS_HIST_DEVICE_BYTES (default 8 GiB) the oldest device chunk is spilled to
+// host memory, so the history can grow like the reference's Python lists do without taking HBM from the LU workspace.
+__global__ void hist_append_kernel(c128* __restrict__ dst, long len, const c128* __restrict__ src, long ld, const int* __restrict__ slots) {
+    const c128* s = src + (long)slots[blockIdx.x] * ld;
+    c128* d = dst + (long)blockIdx.x * len;
+    for (long k = threadIdx.x; k < len; k += blockDim.x) d[k] = s[k];
+}
+
+static void hist_free(maus_ctx* c) {
+    for (auto& h : c->hist) { if (h.dev) (void)hipFree(h.dev); if (h.host) free(h.host); }
+    c->hist.clear(); c->hist_len = 0; c->hist_rows = 0; c->hist_dev_bytes = 0;
+}
+
+int maus_hist_clear(maus_ctx* c) { HIPCHK(c, hipStreamSynchronize(c->st)); hist_free(c); return 0; }
+
+int maus_hist_append(maus_ctx* c, int which, const int* slots, int count, int len, int64_t* first_index_out) {
+    c128* P = pop_array(c, which);
+    if (!P) FAIL(c, "maus_hist_append: population not reserved / bad array id");
+    if (len <= 0 || len > c->ldp) FAIL(c, "maus_hist_append: bad vector length");
+    if (check_slots(c, slots, count)) return -1;
+    if (first_index_out) *first_index_out = c->hist_rows;
+    if (count == 0) return 0;
+    len = (int)c->ldp;                                               // rows are stored whole (u and v of an SVD problem differ in length)
+    c->hist_len = len;
+    const char* be = getenv("MAUS_HIST_DEVICE_BYTES");
+    const size_t budget = be ? (size_t)atoll(be) : ((size_t)8 << 30);
+    const char* ce = getenv("MAUS_HIST_CHUNK_BYTES");                                                          // 256 MiB chunks
+    const long chunk_rows = !c->hist.empty() ? c->hist.front().cap
+                          : std::max<long>(4, (long)((ce ? (size_t)atoll(ce) : ((size_t)256 << 20)) / (sizeof(c128) * (size_t)len)));
+    int done = 0;
+    while (done < count) {
+        if (c->hist.empty() || c->hist.back().rows == c->hist.back().cap) {
+            maus_ctx::HistChunk h; h.cap = chunk_rows;
+            const size_t bytes = sizeof(c128) * (size_t)len * h.cap;
+            while (c->hist_dev_bytes + bytes > budget) {             // spill the oldest device chunk to the host
+                maus_ctx::HistChunk* old = nullptr;
+                for (auto& q : c->hist) if (q.dev) { old = &q; break; }
+                if (!old) break;
+                const size_t ob = sizeof(c128) * (size_t)len * old->cap;
+                old->host = (c128*)malloc(ob);
+                if (!old->host) FAIL(c, "maus_hist_append: out of host memory");
+                HIPCHK(c, hipStreamSynchronize(c->st));
+                HIPCHK(c, hipMemcpy(old->host, old->dev, sizeof(c128) * (size_t)len * old->rows, hipMemcpyDeviceToHost));
+                (void)hipFree(old->dev); old->dev = nullptr; c->hist_dev_bytes -= ob;
+            }
+            HIPCHK(c, hipMalloc((void**)&h.dev, bytes));
+            c->hist_dev_bytes += bytes;
+            c->hist.push_back(h);
+        }
+        auto& h = c->hist.back();
+        const int take = (int)std::min<long>(count - done, h.cap - h.rows);
+        if (upload_slots(c, slots + done, take)) return -1;
+        hipLaunchKernelGGL(hist_append_kernel, dim3(take), dim3(256), 0, c->st, h.dev + (size_t)h.rows * len, (long)len, P, c->ldp, c->d_slots);
+        HIPCHK(c, hipStreamSynchronize(c->st));                       // d_slots is reused by the next call
+        h.rows += take; done += take; c->hist_rows += take;
+    }
+    return 0;
+}
+
+int maus_hist_get(maus_ctx* c, const int64_t* indices, int count, int len, double* host_c128) {
+    if (count < 0 || len <= 0 || len > c->hist_len) FAIL(c, "maus_hist_get: bad arguments");
+    const long chunk_rows = c->hist.empty() ? 1 : c->hist.front().cap;
+    for (int i = 0; i < count; ++i) {
+        const int64_t ix = indices[i];
+        if (ix < 0 || ix >= c->hist_rows) FAIL(c, "maus_hist_get: index out of range");
+        const auto& h = c->hist[(size_t)(ix / chunk_rows)];
+        const size_t off = (size_t)(ix % chunk_rows) * c->hist_len;
+        double* out = host_c128 + 2 * (size_t)i * len;
+        if (h.dev) HIPCHK(c, hipMemcpyAsync(out, h.dev + off, sizeof(c128) * len, hipMemcpyDeviceToHost, c->st));
+        else memcpy(out, h.host + off, sizeof(c128) * len);
+    }
     HIPCHK(c, hipStreamSynchronize(c->st));
     return 0;
 }
@@ -358,22 +438,19 @@ static void finish_status(int G, const int* info, const int* flags, int32_t* sta
 
 
 // MAUS_PERT_MT19937: generator start states for candidates [first, first+g) of the run by binary lifting (over the
-// draw index m, then over the sub-stream index b), then the H build that regenerates the draws (mtdev.hip).
+// draw index m, then over the sub-stream index b), then the H build that regenerates the draws (mtdev.hip).  The plan
+// itself (pure host arithmetic on stream offsets) lives in mtplan.cpp so that it can be built and run under the CPU
+// sanitizers (`make asan`).
 static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* d, int first, int g, int rhs_mode, int lo, int sbi) {
     if ((int)c->mt_bufs.size() <= sbi) c->mt_bufs.resize(sbi + 1);
     maus_ctx::MtBuf& mb = c->mt_bufs[sbi];
     const int n = w.n;
-    const uint64_t two_n2 = 2ull * n * n;
-    if (d->pos < 0 || d->pos > 624) FAIL(c, "maus_mt_desc: bad position");
-    if (d->words_per_candidate % two_n2 || d->lead_words % two_n2 || d->words_per_candidate < 2 * two_n2 || !d->ordinals)
-        FAIL(c, "maus_mt_desc: words_per_candidate / lead_words must be multiples of 2*n*n");
-    // sub-streams per draw: enough workgroups to cover the chip a few times, each at least ~64 blocks long
-    int S = std::max(1, std::min(8, 768 / std::max(1, g)));
-    const uint64_t nn = (uint64_t)n * n;
-    while (S > 1 && nn / S < 64 * 312) --S;
-    { const char* e = getenv("MAUS_MT_SUBSTREAMS"); if (e) S = std::max(1, std::min(16, atoi(e))); }
-    const uint64_t E = (nn + S - 1) / S;                          // elements per sub-stream
-    const int ngen = 2 * g * S;
+    int s_override = 0;
+    { const char* e = getenv("MAUS_MT_SUBSTREAMS"); if (e) s_override = std::max(1, std::min(16, atoi(e))); }
+    MausMtPlan& pl = c->mt_plan;
+    const char* perr = nullptr;
+    if (maus_mt_plan(d, n, first, g, s_override, &pl, &perr)) FAIL(c, perr ? perr : "maus_mt_plan failed");
+    const int ngen = pl.ngen;
     if (ngen > mb.cap) {
         void** ps[] = {(void**)&mb.states, (void**)&mb.base};
         for (auto p : ps) if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -382,59 +459,24 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
         HIPCHK(c, hipMalloc((void**)&mb.base, sizeof(uint32_t) * 624));
         mb.cap = cap;
     }
-    const uint64_t dblocks = two_n2 / 624;
-    const uint64_t dj = dblocks >= 2 ? dblocks - 1 : 0;          // jump stride (blocks) per draw; >= 1 real regeneration follows
-    const uint64_t sblocks = (2 * E) / 624;
-    const uint64_t dj2 = (S > 1 && sblocks >= 2) ? sblocks - 1 : 0;   // jump stride (blocks) per sub-stream
-    std::vector<uint64_t> m(ngen), bsel(ngen);
-    // staging layout: extra[ngen] | rpos[ngen] | selection lists of every lifting level
-    std::vector<int>& hs = c->mt_host;
-    hs.assign(2 * (size_t)ngen, 0);
-    uint64_t maxm = 0, maxb = 0;
-    for (int k = 0; k < g; ++k) {
-        const uint64_t ord = (uint64_t)d->ordinals[first + k];
-        for (int sb = 0; sb < S; ++sb)
-            for (int part = 0; part < 2; ++part) {
-                const int gi = (k * S + sb) * 2 + part;
-                const uint64_t mm = (d->lead_words + ord * d->words_per_candidate) / two_n2 + part;
-                const uint64_t t = (uint64_t)d->pos + mm * two_n2 + 2ull * sb * E;
-                const uint64_t q = t / 624;
-                m[gi] = dj ? mm : 0;
-                bsel[gi] = dj2 ? (uint64_t)sb : 0;
-                const uint64_t ex = q - m[gi] * dj - bsel[gi] * dj2;
-                if (ex > 2000000000ull) FAIL(c, "maus_mt_desc: stream offset too large");
-                hs[gi] = (int)ex;
-                hs[ngen + gi] = (int)(t % 624);
-                maxm = std::max(maxm, m[gi]); maxb = std::max(maxb, bsel[gi]);
-            }
-    }
-    struct Level { size_t off; int count; const int* taps; int ntap16; };
-    std::vector<Level> levels;
-    auto plan = [&](const std::vector<uint64_t>& idx, uint64_t maxv, uint64_t stride_blocks) -> int {
-        for (int bit = 0; stride_blocks && (maxv >> bit); ++bit) {
-            const size_t off = hs.size();
-            for (int i = 0; i < ngen; ++i) if ((idx[i] >> bit) & 1ull) hs.push_back(i);
-            const int cnt = (int)(hs.size() - off);
-            if (!cnt) continue;
-            const uint64_t J = 624ull * stride_blocks * (1ull << bit);
-            auto it = c->mt_taps.find(J);
-            if (it == c->mt_taps.end()) {                       // tap list of x^J mod phi, cached on the device
-                std::vector<uint64_t> poly(312);
-                if (maus_mt_jump_poly(J, poly.data())) FAIL(c, "MT19937 jump polynomial failed");
-                std::vector<int> taps;
-                for (int i = 0; i < 19937; ++i) if ((poly[i >> 6] >> (i & 63)) & 1ull) taps.push_back(i);
-                while (taps.size() % 16) taps.push_back(maus_mt_zero_tap());
-                int* dt = nullptr;
-                HIPCHK(c, hipMalloc((void**)&dt, sizeof(int) * taps.size()));
-                HIPCHK(c, hipMemcpy(dt, taps.data(), sizeof(int) * taps.size(), hipMemcpyHostToDevice));
-                it = c->mt_taps.emplace(J, std::make_pair(dt, (int)(taps.size() / 16))).first;
-            }
-            levels.push_back({off, cnt, it->second.first, it->second.second});
+    struct DevLevel { size_t off; int count; const int* taps; int ntap16; };
+    std::vector<DevLevel> levels;
+    for (const MausMtPlan::Level& L : pl.levels) {
+        auto it = c->mt_taps.find(L.J);
+        if (it == c->mt_taps.end()) {                       // tap list of x^J mod phi, cached on the device
+            std::vector<uint64_t> poly(312);
+            if (maus_mt_jump_poly(L.J, poly.data())) FAIL(c, "MT19937 jump polynomial failed");
+            std::vector<int> taps;
+            for (int i = 0; i < 19937; ++i) if ((poly[i >> 6] >> (i & 63)) & 1ull) taps.push_back(i);
+            while (taps.size() % 16) taps.push_back(maus_mt_zero_tap());
+            int* dt = nullptr;
+            HIPCHK(c, hipMalloc((void**)&dt, sizeof(int) * taps.size()));
+            HIPCHK(c, hipMemcpy(dt, taps.data(), sizeof(int) * taps.size(), hipMemcpyHostToDevice));
+            it = c->mt_taps.emplace(L.J, std::make_pair(dt, (int)(taps.size() / 16))).first;
         }
-        return 0;
-    };
-    if (plan(m, maxm, dj)) return -1;
-    if (plan(bsel, maxb, dj2)) return -1;
+        levels.push_back({L.off, L.count, it->second.first, it->second.second});
+    }
+    const std::vector<int>& hs = pl.hs;
     if (hs.size() > mb.int_cap) {
         if (mb.ints) { (void)hipFree(mb.ints); mb.ints = nullptr; }
         const size_t cap = hs.size() * 2;
@@ -445,10 +487,10 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
     HIPCHK(c, hipMemcpyAsync(mb.ints, hs.data(), sizeof(int) * hs.size(), hipMemcpyHostToDevice, w.st));
     HIPCHK(c, hipStreamSynchronize(w.st));                       // staging (hs, d->key) is reusable from here on
     maus_mt_copy_states(w.st, mb.states, mb.base, ngen);
-    for (const Level& L : levels) maus_mt_jump(w.st, mb.states, mb.ints + L.off, L.count, L.taps, L.ntap16);
+    for (const DevLevel& L : levels) maus_mt_jump(w.st, mb.states, mb.ints + L.off, L.count, L.taps, L.ntap16);
     const int* d_extra = mb.ints; const int* d_rpos = mb.ints + ngen;
     prof_tick(c, KC_BUILD, 0, 0, 0);
-    maus_build_h_mt(w.st, c->A, n, w.npad, w.ldh, w.strideH, w.H, g, S, (long)E, c->d_c1 + lo, c->d_r1 + lo, rhs_mode, c->X, c->ldp,
+    maus_build_h_mt(w.st, c->A, n, w.npad, w.ldh, w.strideH, w.H, g, pl.S, (long)pl.E, c->d_c1 + lo, c->d_r1 + lo, rhs_mode, c->X, c->ldp,
                     c->d_slots + lo, c->b, mb.states, d_extra, d_rpos, w.flags);
     prof_tick(c, KC_BUILD, 1, 0, 32.0 * w.npad * w.ldh * g);
     return 0;

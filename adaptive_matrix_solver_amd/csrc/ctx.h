@@ -9,6 +9,7 @@
 
 // ---- kernels / drivers implemented in the other translation units ---------------------
 #include "luws.h"
+#include "mtplan.h"
 void maus_lu_factor(const LuWs& w, int nbo);
 void maus_lu_backsolve(const LuWs& w, c128* Wpop, long ldw, const int* d_slots, c128* xout_dense);
 void maus_build_h(const LuWs& w, const c128* A, const c128* d_shift, const double* d_psi, int rhs_mode,
@@ -67,11 +68,14 @@ struct maus_ctx {
     struct MtBuf { uint32_t* states = nullptr; int* ints = nullptr; uint32_t* base = nullptr; int cap = 0; size_t int_cap = 0; };
     std::vector<MtBuf> mt_bufs;
     std::map<uint64_t, std::pair<int*, int>> mt_taps;   // J -> (device tap list of x^J mod phi, #taps/16)
-    std::vector<int> mt_host;                           // staging for the per-level selections
+    MausMtPlan mt_plan;                                 // host plan + staging image of the current sub-batch (mtplan.cpp)
     // sub-batch streams: bandwidth-bound phases (panel, swaps, trsm) of one sub-batch overlap the
     // MFMA-bound trailing updates of another
     std::vector<hipStream_t> lu_st; std::vector<hipEvent_t> lu_done; hipEvent_t ev_stage = nullptr;
     hipStream_t prof_st = nullptr;
+    // history store (SURVEY f-4): rows appended on the device, oldest chunks spilled to host memory beyond a byte budget
+    struct HistChunk { c128* dev = nullptr; c128* host = nullptr; long rows = 0; long cap = 0; };
+    std::vector<HistChunk> hist; long hist_len = 0; long hist_rows = 0; size_t hist_dev_bytes = 0;
     // generic scratch (host-GEMM / host-LU test entry points, GMRES)
     void* scratch = nullptr; size_t scratch_bytes = 0;
     // measurement

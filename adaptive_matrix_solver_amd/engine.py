@@ -163,6 +163,7 @@ class DeviceEngine:
         self._bound = None                      # matrix object currently on the device
         self._bound_b = None
         self._eig_cache = None                  # (matrix obj, evals) for the Hermitian shortcut
+        self._typ_entry = None                  # (matrix obj, rms entry) for pert_matters
         self._free = []
         self._next_slot = 0
         self.steps_executed = 0
@@ -185,6 +186,15 @@ class DeviceEngine:
             self._free = []
             self._next_slot = 0
             self._bound_b = None
+
+    def pert_matters(self, psi) -> np.ndarray:
+        """AMS:49-52 adds 0.15*psi*((U1-.5)+i(U2-.5)) to H for GMRES as for the direct solve.  The device GMRES shares one
+        A between all candidates and leaves the random term out while it is below the rounding of a matvec
+        (|term| <= 0.075 psi < half an ulp of a typical entry of A); beyond that H_k is materialised (maus_gmres_pert)."""
+        if self._typ_entry is None or self._typ_entry[0] is not self._bound:
+            A = self._bound
+            self._typ_entry = (A, float(np.linalg.norm(A)) / np.sqrt(max(1, A.size)))
+        return 0.075 * np.abs(np.asarray(psi, dtype=np.float64)) >= 2.0 ** -53 * self._typ_entry[1]
 
     def bind_rhs(self, b):
         if b is None or b is self._bound_b:
@@ -235,6 +245,25 @@ class DeviceEngine:
             if U is not None:
                 c._hu = U[k]
             c._host_valid = True
+
+    def _stage_history(self, cands) -> None:
+        """Before SolutionCandidate._record_history (AMS:303-304): small problems get their host mirrors refreshed with
+        one transfer; above n = 512 the vectors are appended device-to-device to the history store and the candidates
+        keep a reference (SURVEY f-4: device-backed param_history, pulled on access)."""
+        from .solver import ProblemType
+        rec = [c for c in cands if c._record]
+        eager = [c for c in rec if not c._lazy_hist]
+        if eager:
+            self._bulk_pull(eager)
+        lazy = [c for c in rec if c._lazy_hist]
+        if lazy:
+            slots = [c._slot for c in lazy]
+            svd = lazy[0].problem_type == ProblemType.SVD
+            lv = lazy[0]._len_v()
+            iv = self.ctx.hist_append(POP_X, slots, lv)
+            iu = self.ctx.hist_append(POP_U, slots, lazy[0].M_rows) if svd else None
+            for k, c in enumerate(lazy):
+                c._hist_ref = ((iu + k, c.M_rows), (iv + k, lv)) if svd else ((iv + k, lv),)
 
     # ---- perturbation mode ---------------------------------------------------------------
     def _pert(self, n: int) -> int:
@@ -302,6 +331,23 @@ class DeviceEngine:
         loc = np.zeros((len(mine), 3))
         if mine:
             info, inner, status = self.ctx.gmres([cands[k]._slot for k in mine], shift[mine], psi[mine], rhs_mode, use_j[mine])
+            loc = np.column_stack([info, inner, status]).astype(np.float64)
+        f = self._exchange(cands, loc).astype(np.int32)
+        return f[:, 0], f[:, 1], f[:, 2]
+
+    def d_gmres_pert(self, cands, shift, psi, rhs_mode, want_j, pert, pert_data):
+        mine = self._mine(cands)
+        if mine is None:
+            info, inner, status, _ = self.ctx.gmres_pert([c._slot for c in cands], shift, psi, rhs_mode, want_j, pert, pert_data)
+            return info, inner, status
+        loc = np.zeros((len(mine), 3))
+        if mine:
+            if pert == PERT_MT19937:
+                sub = (pert_data[0], pert_data[1], pert_data[2], np.asarray(pert_data[3])[mine])
+            else:
+                sub = None if pert_data is None else pert_data[mine]
+            info, inner, status, _ = self.ctx.gmres_pert([cands[k]._slot for k in mine], shift[mine], psi[mine], rhs_mode,
+                                                         want_j[mine], pert, sub)
             loc = np.column_stack([info, inner, status]).astype(np.float64)
         f = self._exchange(cands, loc).astype(np.int32)
         return f[:, 0], f[:, 1], f[:, 2]
@@ -434,6 +480,8 @@ class DeviceEngine:
         for k, c in enumerate(cands):
             c.lambda_k = lam[k]
             c._invalidate()
+        self._stage_history(cands)
+        for k, c in enumerate(cands):
             c.residual_k = res[k]
             c.state = S.CONVERGED
             c.stuck_counter = 0
@@ -592,8 +640,11 @@ class DeviceEngine:
                 status = self.d_lu_solve(run, shift, psi0, 0 if is_eig else 1, pert, pert_data)
                 ok = status == 0
             else:
-                ok = self._gmres_batch(run, shift, psi0, stuck, is_eig)
-                if pert != PERT_UNIFORM and not ok.all():
+                ok = self._gmres_batch(run, shift, psi0, stuck, is_eig, pert, pert_data)
+                # escalated psi: the GMRES iterates depend on the draws (dense mode), so a failed attempt -- whose retry
+                # moves the stream position of everybody behind it -- ends the run like any other RNG event
+                dense_any = pert != PERT_NONE and bool(self.pert_matters(psi0).any())
+                if pert != PERT_UNIFORM and not ok.all() and not dense_any:
                     # AMS:99-103 in batch: a failed attempt 0 with the preferred (GMRES) method is retried with the
                     # direct solver at the same attempt index.  For ill-conditioned ("Fragile") systems that is the
                     # common case, not the exception -- one batched LU instead of one ladder per candidate.  The
@@ -671,16 +722,29 @@ class DeviceEngine:
                         cc._restore_device()
                 i += 1
 
-    def _gmres_batch(self, run, shift, psi0, stuck, is_eig):
+    def _gmres_batch(self, run, shift, psi0, stuck, is_eig, pert=PERT_NONE, pert_data=None):
         """First GMRES attempt of a run (AMS:60-90 with tol->rtol).  Returns ok[]."""
-        psi_eff = psi0
-        use_j = np.zeros(len(run), dtype=np.int32)
+        ok = np.zeros(len(run), dtype=bool)
         cand_j = stuck > 1                                              # AMS:65
-        if np.any(cand_j):
-            okj = self.ctx.jacobi_check(shift, psi_eff)                 # AMS:72
-            use_j = (cand_j & okj).astype(np.int32)
-        info, inner, status = self.d_gmres(run, shift, psi_eff, 0 if is_eig else 1, use_j)
-        return (info == 0) & (status == 0)
+        dense = self.pert_matters(psi0) if pert != PERT_NONE else np.zeros(len(run), dtype=bool)
+        L = np.nonzero(~dense)[0]
+        if L.size:                                                      # random term below the rounding of a matvec
+            use_j = np.zeros(L.size, dtype=np.int32)
+            if np.any(cand_j[L]):
+                okj = self.ctx.jacobi_check(shift[L], psi0[L])          # AMS:72
+                use_j = (cand_j[L] & okj).astype(np.int32)
+            info, inner, status = self.d_gmres([run[k] for k in L], shift[L], psi0[L], 0 if is_eig else 1, use_j)
+            ok[L] = (info == 0) & (status == 0)
+        D = np.nonzero(dense)[0]
+        if D.size:                                                      # escalated psi: the reference's full H_solve
+            if pert == PERT_MT19937:
+                pd = (pert_data[0], pert_data[1], pert_data[2], np.asarray(pert_data[3])[D])
+            else:
+                pd = pert_data[D]
+            info, inner, status = self.d_gmres_pert([run[k] for k in D], shift[D], psi0[D], 0 if is_eig else 1,
+                                                    cand_j[D].astype(np.int32), pert, pd)
+            ok[D] = (info == 0) & (status == 0)
+        return ok
 
     def _attempt(self, c, method, shift, psi, is_eig, n, pert, stuck):
         """One solve attempt for one candidate on the device.  Raises like AMS:59/90/94-95."""
@@ -704,10 +768,14 @@ class DeviceEngine:
         elif method == GMRES:
             if self.gmres_compat == "scipy-legacy":
                 raise TypeError("gmres() got an unexpected keyword argument 'tol'")
-            use_j = np.zeros(1, dtype=np.int32)
-            if stuck > 1 and self.ctx.jacobi_check(sh, ps)[0]:
-                use_j[0] = 1
-            info, inner, status = self.d_gmres([c], sh, ps, 0 if is_eig else 1, use_j)
+            if pert != PERT_NONE and self.pert_matters(ps)[0]:
+                info, inner, status = self.d_gmres_pert([c], sh, ps, 0 if is_eig else 1,
+                                                        np.array([1 if stuck > 1 else 0], dtype=np.int32), pert, pert_data)
+            else:
+                use_j = np.zeros(1, dtype=np.int32)
+                if stuck > 1 and self.ctx.jacobi_check(sh, ps)[0]:
+                    use_j[0] = 1
+                info, inner, status = self.d_gmres([c], sh, ps, 0 if is_eig else 1, use_j)
             if status[0] == -1:
                 raise ValueError("array must not contain infs or NaNs")
             if info[0] != 0:
@@ -789,8 +857,7 @@ class DeviceEngine:
                 finite[id(c)] = bool(fin[k])
         self.bind_matrix(A)
         thr = strat.get("current_convergence_threshold", CONVERGENCE_RESIDUAL_TOL)
-        if any(c._record for c in cands):
-            self._bulk_pull([c for c in cands if c._record])
+        self._stage_history(cands)
         for c in cands:
             c._record_history()                                          # AMS:303-304
             if c.prev_residual > 1e-10:                                  # AMS:306-316

@@ -137,11 +137,20 @@ class InverseIterateSolver:
                 elif method == "iterative_gmres":
                     if self.gmres_compat == "scipy-legacy":
                         raise TypeError("gmres() got an unexpected keyword argument 'tol'")
-                    use_j = np.zeros(1, dtype=np.int32)
-                    if candidate_stuck_counter > 1 and n > 0 and ctx.jacobi_check(zero, ps)[0]:     # AMS:65-72
-                        use_j[0] = 1
-                    rec["jacobi"] = bool(use_j[0])
-                    info, inner, status = ctx.gmres([0], zero, ps, 1, use_j)
+                    typ = float(np.linalg.norm(A_target)) / np.sqrt(max(1, A_target.size))
+                    if pmode != _cabi.PERT_NONE and 0.075 * abs(ps[0]) >= 2.0 ** -53 * typ:
+                        # escalated psi: the random term of AMS:49-50 is no longer below the rounding of a matvec ->
+                        # GMRES against the materialised H_solve (engine.DeviceEngine.pert_matters states the rule)
+                        want = np.array([1 if (candidate_stuck_counter > 1 and n > 0) else 0], dtype=np.int32)
+                        info, inner, status, jac = ctx.gmres_pert([0], zero, ps, 1, want, pmode, pert_data)
+                        use_j = jac.astype(np.int32)
+                        rec["jacobi"], rec["dense"] = bool(jac[0]), True
+                    else:
+                        use_j = np.zeros(1, dtype=np.int32)
+                        if candidate_stuck_counter > 1 and n > 0 and ctx.jacobi_check(zero, ps)[0]:     # AMS:65-72
+                            use_j[0] = 1
+                        rec["jacobi"] = bool(use_j[0])
+                        info, inner, status = ctx.gmres([0], zero, ps, 1, use_j)
                     rec["info"], rec["inner"] = int(info[0]), int(inner[0])
                     if status[0] == -1:
                         raise ValueError("array must not contain infs or NaNs")
@@ -166,6 +175,40 @@ class InverseIterateSolver:
                 num_psi_attempts += 1
         raise RuntimeError(f"InverseIterateSolver failed all {self.max_attempts} attempts for "
                            f"{self.preferred_method} and {self.fallback_method}.")
+
+
+class _HistRef:
+    """One recorded iterate whose vectors live in the context's history store (device, spilled to host when old)."""
+    __slots__ = ("ctx", "scalar", "rows")
+
+    def __init__(self, ctx, scalar, rows):
+        self.ctx, self.scalar, self.rows = ctx, scalar, rows          # rows: ((history index, length), ...)
+
+    def resolve(self):
+        vecs = tuple(self.ctx.hist_get([ix], ln)[0] for ix, ln in self.rows)
+        return vecs if self.scalar is None else (self.scalar,) + vecs
+
+
+class _LazyHistory(list):
+    """param_history (AMS:126, 303-304).  Entries recorded by the batched step above n = 512 are references into the
+    device-backed history store and become the reference's tuples (lambda, v) / (x,) / (sigma, u, v) when they are
+    read; everything else about the list (len, append, iteration, slicing) is a plain list."""
+
+    def _get(self, i):
+        e = list.__getitem__(self, i)
+        if isinstance(e, _HistRef):
+            e = e.resolve()
+            list.__setitem__(self, i, e)
+        return e
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._get(k) for k in range(*i.indices(len(self)))]
+        return self._get(i if i >= 0 else i + len(self))
+
+    def __iter__(self):
+        for k in range(len(self)):
+            yield self._get(k)
 
 
 # ==========================================================================================
@@ -199,7 +242,11 @@ class SolutionCandidate:
         self._dev_valid = False        # device rows are current
         self._slot = None
         self._engine = None
-        self._record = (max(self.M_rows, self.M_cols) <= 512) if record_history is None else bool(record_history)
+        # param_history records every iterate like the reference (record_history=False: residual_history only); above
+        # n = 512 the vectors stay on the device (history store) until somebody reads them
+        self._record = True if record_history is None else bool(record_history)
+        self._lazy_hist = max(self.M_rows, self.M_cols) > 512
+        self._hist_ref = None
         self.state = SolutionCandidate.State.EXPLORING
         self.w_k = initial_weight
         self.residual_k = float("inf")
@@ -208,7 +255,7 @@ class SolutionCandidate:
         self.stuck_counter = 0
         self.local_psi_retries_needed = 0
         self.num_resets = 0
-        self.param_history = []
+        self.param_history = _LazyHistory()
         self.residual_history = []
         (engine or DeviceEngine.default()).attach(self)
         self.initialize_random_solution()                     # overwrites any seeds (AMS:127)
@@ -323,9 +370,15 @@ class SolutionCandidate:
         self.residual_history.append(self.residual_k)
 
     def _record_history(self):
-        """AMS:303-304 (vectors are recorded only when record_history is on)."""
+        """AMS:303-304.  The engine stages the vectors first (DeviceEngine._stage_history): a host pull for small
+        problems, a device-to-device append to the history store (self._hist_ref) above n = 512."""
         if self._record:
-            self.param_history.append(self.get_current_solution_params())
+            if self._hist_ref is not None:
+                scalar = {ProblemType.EIGENVALUE: self.lambda_k, ProblemType.SVD: self.sigma_k}.get(self.problem_type)
+                self.param_history.append(_HistRef(self._engine.ctx, scalar, self._hist_ref))
+                self._hist_ref = None
+            else:
+                self.param_history.append(self.get_current_solution_params())
         self.residual_history.append(self.residual_k)
 
     # ---- AMS:145-331 -----------------------------------------------------------------------------
@@ -757,6 +810,16 @@ class MAUS_Solver:
                     raise ValueError("b_vector is None.")
                 if self.N_rows != self.b.shape[0]:
                     raise ValueError("A,b shape mismatch.")
+                if self.N_rows > 512 and hasattr(self.engine.ctx, "lu_solve"):
+                    # the batched LU (LAPACK's pivot order) on the device instead of a host zgesv: the same answer to
+                    # conditioning, in milliseconds at n = 4096
+                    if not (np.all(np.isfinite(self.M)) and np.all(np.isfinite(self.b))):
+                        raise ValueError("array must not contain infs or NaNs")
+                    x, st = self.engine.ctx.lu_solve(self.M, self.b)
+                    if st[0] > 0:
+                        raise np.linalg.LinAlgError("Matrix is singular.")
+                    self.engine.bind_matrix(self.M)
+                    return x[0]
                 return sla.solve(self.M, self.b, assume_a="general")
             return sorted(sla.svd(self.M, compute_uv=False).tolist(), reverse=True)
         except (np.linalg.LinAlgError, ValueError) as e:
@@ -773,14 +836,21 @@ class MAUS_Solver:
         return np.linalg.norm(M @ t[2] - t[0] * t[1]) + np.linalg.norm(M.conj().T @ t[1] - t[0] * t[2])
 
     def evolve(self, max_iterations=100, *, reference_check=None):
-        """AMS:551-608.  `reference_check`: run the reference's SciPy prologue and the closing comparison (None = only
-        for n <= 1024, where the host O(n^3) solve is cheap; True / False force it)."""
+        """AMS:551-608.  `reference_check` (default on, as in the reference): the "true solution" prologue (AMS:554-570)
+        and the closing comparison.  Linear systems above n = 512 are solved by the device LU; eigenvalues and singular
+        values come from SciPy on the host -- O(n^3) there (about a minute at n = 4096), reported when it takes more than
+        a few seconds; False skips it."""
         print(f"--- Starting MAUS Evolution for {max_iterations} iterations ({self.problem_type.name}) ---")
         self.true_solution = None
         if reference_check is None:
-            reference_check = max(self.N_rows, self.N_cols) <= 1024
+            reference_check = True
         if reference_check:
+            import time
+            t0 = time.perf_counter()
             self.true_solution = self._reference_solution()
+            if time.perf_counter() - t0 > 5.0:
+                print(f"(reference solution for the closing comparison: {time.perf_counter() - t0:.1f} s on the host; "
+                      f"evolve(reference_check=False) skips it)")
         for i in range(max_iterations):
             self.loop_body(i + 1)
             target_sols_disp = self.N_diag

@@ -117,6 +117,9 @@ def main():
                     help="HIP-event bracketing of kernel launches in the timed region: every K>=256 zgemm launch (default), "
                          "every launch of every kernel (costs 3-5 %% of throughput), or none")
     ap.add_argument("--cpu-budget", type=float, default=40.0)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start the ranks, form the process group, all-gather the rank ids, print {n_gpus} and exit "
+                         "without touching a GPU (tests/test_dist_gloo.py checks the --gpus N self-launch with it)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -131,6 +134,16 @@ def main():
                  f"(python bench.py --gpus N does that itself)")
     comm = None
     backend = os.environ.get("MAUS_DIST_BACKEND", "nccl")
+    if args.launch_check:
+        ranks = [0]
+        if world > 1:
+            from adaptive_matrix_solver_amd import dist as mdist
+            comm = mdist.init_from_env(backend)
+            ranks = comm.allgather_rows(np.array([[float(rank)]]), [1] * world)[:, 0].astype(int).tolist()
+            comm.barrier()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": ranks, "backend": backend if world > 1 else None}))
+        return
     if world > 1:
         from adaptive_matrix_solver_amd import dist as mdist
         # nccl == RCCL over xGMI; MAUS_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsal

@@ -91,6 +91,15 @@ int maus_pop_get(maus_ctx* ctx, int which, const int* slots, int count, double* 
  * would continue. */
 int maus_pop_copy(maus_ctx* ctx, int which_dst, int which_src, const int* slots, int count);
 
+/* ---- device-backed history (AMS:126, 303-304: param_history keeps every iterate of every candidate) ---- */
+/* Append the first `len` entries of rows `slots` of population array `which` to the context's history store
+ * (device-to-device, no host traffic); the rows get consecutive indices starting at *first_index_out.  Beyond
+ * MAUS_HIST_DEVICE_BYTES (default 8 GiB) the oldest rows are spilled to host memory.  maus_hist_get fetches rows by
+ * index (from wherever they live) into host_c128[count][len]; maus_hist_clear drops everything. */
+int maus_hist_append(maus_ctx* ctx, int which, const int* slots, int count, int len, int64_t* first_index_out);
+int maus_hist_get(maus_ctx* ctx, const int64_t* indices, int count, int len, double* host_c128);
+int maus_hist_clear(maus_ctx* ctx);
+
 /* ---- phases of update_solution_step, batched over `count` candidates ---- */
 /* Y[slot] = A @ X[slot]; num = vdot(v, A@v), den = vdot(v, v)      AMS:264-268.
  * num_c128: count complex; den_c128: count complex (imag is the rounded sum, ~0). */

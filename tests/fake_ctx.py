@@ -209,3 +209,49 @@ class FakeContext:
                 status[k] = -2
             self.pop[2][s, :n] = x
         return info, inner, status
+
+    def gmres_pert(self, slots, shift, psi, rhs_mode, want_jacobi, pert_mode, pert_data, rtol=1e-8, restart=20, maxiter=50):
+        """NumPy double of maus_gmres_pert: GMRES against H_solve including the random term (AMS:49-52, 89)."""
+        n = self.rows
+        info = np.zeros(len(slots), dtype=np.int32)
+        inner = np.zeros(len(slots), dtype=np.int32)
+        status = np.zeros(len(slots), dtype=np.int32)
+        jac = np.zeros(len(slots), dtype=bool)
+        for k, s in enumerate(slots):
+            target = self.A - shift[k] * np.eye(n, dtype=np.complex128) if rhs_mode == 0 else self.A
+            ps = np.complex128(psi[k])
+            reg = ps * np.eye(n, dtype=np.complex128)
+            if pert_mode == 1:
+                reg = reg + (pert_data[k, 0] - 0.5 + 1j * (pert_data[k, 1] - 0.5)) * ps * 0.15
+            H = target + reg
+            rhs = self.pop[0][s, :n].copy() if rhs_mode == 0 else self.b
+            if not (np.all(np.isfinite(H)) and np.all(np.isfinite(rhs))):
+                status[k] = -1
+                continue
+            inv_d = None
+            if want_jacobi[k]:
+                d = np.diag(H)
+                with np.errstate(all="ignore"):
+                    inv = 1.0 / d
+                if np.all(np.isfinite(inv)) and np.all(np.abs(d) > 1e-12):
+                    inv_d, jac[k] = inv, True
+            x, inf, inn, cyc = orc.gmres_restated(H, rhs, rhs, inv_d, rtol=rtol, maxiter=maxiter, restart=restart)
+            info[k], inner[k] = inf, inn
+            if inf == 0 and not np.all(np.isfinite(x)):
+                status[k] = -2
+            self.pop[2][s, :n] = x
+        return info, inner, status, jac
+
+    def hist_append(self, which, slots, length):
+        if not hasattr(self, "_hist"):
+            self._hist = []
+        first = len(self._hist)
+        for sl in slots:
+            self._hist.append(self.pop[which][sl].copy())
+        return first
+
+    def hist_get(self, indices, length):
+        return np.array([self._hist[i][:length] for i in indices], dtype=np.complex128).reshape(len(indices), length)
+
+    def hist_clear(self):
+        self._hist = []

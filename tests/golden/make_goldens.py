@@ -163,6 +163,12 @@ def solve_fixtures(mod):
                 run(f"gmres_n{n}_s{stuck}", n, stuck, 77 + n + stuck, "iterative_gmres", 10.0, True)
         # hard spectrum, no Jacobi (stuck<=1): GMRES exhausts 50x20 inner iterations -> falls back to LU
         run("gmresfb_n32_s0", 32, 0, 123, "iterative_gmres", 10.0, True)
+        # escalated psi (the GMRES analogue of bigpsi): base psi 1e-5, stuck 2 -> psi = 4.6e-5; the random term
+        # 0.15*psi*((U1-.5)+i(U2-.5)) of AMS:49-50 is part of H_solve in the GMRES branch too (AMS:52, 89) and is
+        # visible in the iterate at the 1e-6 level
+        for n in (32, 128):
+            run(f"gmresbig_n{n}_s2", n, 2, 555 + n, "iterative_gmres", 1e15, True)
+        run("gmresbig_n32_s0", 32, 0, 556, "iterative_gmres", 1e15, True)
     finally:
         mod.spla = real
     # unshimmed: GMRES preferred -> TypeError swallowed -> LU (container SciPy behaviour, F2)

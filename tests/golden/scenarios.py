@@ -118,6 +118,9 @@ def solve_case_inputs(key):
     if key.startswith("gmres_n"):
         n = int(key.split("_")[1][1:])
         return wide_diag_system(n, 300 + n, decades=3.0)
+    if key.startswith("gmresbig_n"):
+        n = int(key.split("_")[1][1:])
+        return wide_diag_system(n, 400 + n, decades=3.0)
     if key.startswith("gmresfb_n"):
         n = int(key.split("_")[1][1:])
         return wide_diag_system(n, 300 + n, decades=7.0)

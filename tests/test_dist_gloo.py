@@ -77,3 +77,33 @@ def test_owner_partition_is_contiguous_and_balanced():
             assert len(own) == n and list(own) == sorted(own)
             sizes = np.bincount(own, minlength=world)
             assert sizes.max() - sizes.min() <= 1
+
+
+def _bench(args, env_extra=None, timeout=240):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus N` outside torchrun: the parent starts N child ranks before touching any GPU and rank 0
+    reports n_gpus = N (--launch-check stops after the process group's first all-gather; gloo on CPU here)."""
+    r = _bench(["--gpus", "2", "--launch-check"], {"MAUS_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout                                   # ONE JSON line, from rank 0
+    rec = json.loads(line[0])
+    assert rec == {"launch_check": True, "n_gpus": 2, "ranks": [0, 1], "backend": "gloo"}
+    # a single rank needs no launcher
+    r1 = _bench(["--gpus", "1", "--launch-check"])
+    assert r1.returncode == 0 and json.loads(r1.stdout.strip())["n_gpus"] == 1
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r = _bench(["--gpus", "4", "--launch-check"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0",
+                                                   "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -1,0 +1,122 @@
+"""SURVEY f-4 on the GPU: MAUS_Solver.evolve() (AMS:551-608, F1 fixed) against the oracle's loop -- converged solutions
+and the printed report -- and the device-backed lazy param_history (AMS:126, 303-304) above n = 512."""
+import io
+import os
+import random
+import re
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+import scenarios
+from oracle import maus_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+KIND = {"eig": orc.EIGENVALUE, "lin": orc.SOLVE_LINEAR_SYSTEM, "svd": orc.SVD}
+
+
+def _oracle_evolve(name, iters):
+    spec = scenarios.TRAJECTORIES[name]
+    A, b = scenarios.build(spec)
+    orc.seed_all(spec["seed"])
+    pop = orc.new_population(A, KIND[spec["kind"]], b=b, n_cands=spec["P"], tol=spec["tol"])
+    for _ in range(iters):
+        orc.loop_body(pop)
+    return A, b, pop
+
+
+@pytest.mark.parametrize("name,iters", [("lap8", 60), ("svd5x4", 30), ("lin24", 12)])
+def test_evolve_converged_solutions_and_report_against_the_oracle(name, iters):
+    from adaptive_matrix_solver_amd.solver import MAUS_Solver, ProblemType, SolutionCandidate
+    spec = scenarios.TRAJECTORIES[name]
+    A, b, pop = _oracle_evolve(name, iters)
+    np.random.seed(spec["seed"]); random.seed(spec["seed"]); SolutionCandidate._candidate_id_counter = 0
+    PT = {"eig": ProblemType.EIGENVALUE, "lin": ProblemType.SOLVE_LINEAR_SYSTEM, "svd": ProblemType.SVD}[spec["kind"]]
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        solver = MAUS_Solver(A, PT, b_vector=b, initial_num_candidates=spec["P"], global_convergence_tol=spec["tol"])
+        solver.evolve(max_iterations=iters)
+    out = buf.getvalue()
+    # the loop ran all iterations on both sides (no early convergence in these scenarios) and ends in the same state
+    assert f"--- Starting MAUS Evolution for {iters} iterations ({PT.name}) ---" in out
+    assert [c.id for c in solver.candidates] == [c.cid for c in pop.cands]
+    assert solver.num_distinct_converged_solutions == pop.n_distinct
+    assert abs(solver.landscape_energy - pop.energy) <= 1e-9
+    # converged_solutions (AMS:432-451): same solutions in the same order
+    assert len(solver.converged_solutions) == len(pop.converged)
+    for got, ref in zip(solver.converged_solutions, pop.converged):
+        assert len(got) == len(ref)
+        for g, r in zip(got, ref):
+            g, r = np.asarray(g), np.asarray(r)
+            if g.ndim == 0:
+                assert abs(g - r) <= 1e-9 * max(1.0, abs(r))
+            else:
+                assert 1.0 - abs(np.vdot(g, r)) / (np.linalg.norm(g) * np.linalg.norm(r)) <= 1e-7
+                assert abs(np.linalg.norm(g) - np.linalg.norm(r)) <= 1e-7 * np.linalg.norm(r)
+    # the periodic line of the last iteration (AMS:581-582)
+    m = re.search(rf"Iter {iters}/{iters}: Energy=([0-9.]+), AvgRes=([0-9.e+-]+), Conv=(\d+)/(\d+), Stab=(\w+)", out)
+    assert m, out[-600:]
+    assert float(m.group(1)) == float(f"{pop.energy:.2f}")
+    assert int(m.group(3)) == pop.n_distinct
+    assert m.group(5) == pop.know["numerical_stability_state"]
+    assert abs(float(m.group(2)) - pop.avg_resid) <= 1e-2 * max(pop.avg_resid, 1e-300) + 1e-12
+    # final report (AMS:587-596): one line per converged solution, sorted as the reference sorts, residual recomputed
+    tag = {"eig": "  Eig ", "lin": "  LinSolve ", "svd": "  SVD "}[spec["kind"]]
+    lines = [l for l in out.splitlines() if l.startswith(tag)]
+    assert len(lines) == len(pop.converged)
+    assert "Final Report:" in out and "--- MAUS Evolution COMPLETE ---" in out
+    sols = list(pop.converged)
+    if spec["kind"] == "eig":
+        sols.sort(key=lambda x: (x[0].real, x[0].imag))
+        for l, t in zip(lines, sols):
+            assert f"λ={t[0]:.6e}"[:-6] in l                       # same eigenvalue to the printed precision's head
+            assert float(l.split("Res=")[1]) <= 10 * spec["tol"]
+    elif spec["kind"] == "svd":
+        sols.sort(key=lambda x: -x[0].real)
+        for l, t in zip(lines, sols):
+            assert abs(float(l.split("σ=")[1].split(",")[0]) - float(np.real(t[0]))) <= 1e-6 * max(1.0, abs(t[0]))
+    else:
+        for l, t in zip(lines, sols):
+            assert abs(float(l.split("X_norm1=")[1].split(",")[0]) - np.linalg.norm(t[0], 1)) <= 1e-5 * np.linalg.norm(t[0], 1)
+    # the SciPy prologue ran (default on) and the closing comparison is printed whenever something converged
+    assert solver.true_solution is not None
+    if pop.n_distinct > 0 and pop.converged:
+        assert "--- Comparison to NumPy ---" in out
+
+
+def test_param_history_is_device_backed_and_lazy_above_512(monkeypatch):
+    """n = 640: the step appends the vectors to the device history store (no pull); reading param_history materialises
+    the reference's (lambda, v) tuples, also after old chunks were spilled to host memory."""
+    from adaptive_matrix_solver_amd.solver import MAUS_Solver, ProblemType, SolutionCandidate, _HistRef
+    monkeypatch.setenv("MAUS_HIST_CHUNK_BYTES", str(16 * 640 * 16))        # 16 rows per chunk
+    monkeypatch.setenv("MAUS_HIST_DEVICE_BYTES", str(3 * 16 * 640 * 16))   # 3 chunks on the device, the rest spilled
+    n, P, iters = 640, 10, 4
+    A = scenarios.ginibre(n, 640, None)
+    np.random.seed(9); random.seed(9); SolutionCandidate._candidate_id_counter = 0
+    solver = MAUS_Solver(A, ProblemType.EIGENVALUE, initial_num_candidates=P, quiet=True)
+    seen = {c.id: [(complex(c.lambda_k), np.array(c.v_k))] for c in solver.candidates}
+    for it in range(iters):
+        solver._update_global_diagnostics(it + 1)
+        solver._adjust_global_strategy(it + 1)
+        active = [c for c in solver.candidates if c.state not in (c.State.CONVERGED, c.State.RETIRED)]
+        solver.step_population()
+        for c in active:
+            seen[c.id].append((complex(c.lambda_k), np.array(c.v_k)))
+        solver._manage_candidates(it + 1)
+        for c in solver.candidates:                                  # freshly spawned: the entry recorded at construction
+            seen.setdefault(c.id, [(complex(c.lambda_k), np.array(c.v_k))])
+    checked = 0
+    for c in solver.candidates:
+        hist = c.param_history
+        assert len(hist) == len(seen[c.id]) == len(c.residual_history)
+        raw = list.__getitem__(hist, len(hist) - 1)
+        if len(hist) > 1:
+            assert isinstance(raw, _HistRef)                        # not pulled until somebody reads it
+        for k, (lam, v) in enumerate(seen[c.id]):
+            hl, hv = hist[k]
+            assert complex(hl) == lam and np.array_equal(np.asarray(hv), v), (c.id, k)
+            checked += 1
+        assert not isinstance(list.__getitem__(hist, len(hist) - 1), _HistRef)   # cached after the read
+    assert checked > P * iters                                       # > 3 device chunks: the oldest were read from the host spill

@@ -127,3 +127,53 @@ def test_two_sub_batch_streams_keep_their_own_generator_state(ctx, n, count):
         W2 = ctx.pop_get(2, slots, n)
         assert (s1 == 0).all() and (s2 == 0).all()
         assert np.array_equal(W1, W2), f"rep {rep}: {np.argwhere(np.any(W1 != W2, axis=1)).ravel()[:8]}"
+
+
+@pytest.mark.parametrize("pert_mode", ["uniform", "mt19937"])
+def test_e4_tiny_norm_reinit_moves_the_draws_of_the_candidates_behind_it(pert_mode):
+    """E4 (AMS:283): a relaxed update with a tiny norm re-initialises the vector from 2 x rand(N), which shifts the
+    rand(N,N) draws of every candidate stepped after it.  Forced here with a matrix scaled by 1e13 and alpha = 1 for two
+    of eight candidates (their update is w itself, ||w|| ~ 1e-12).  With device-regenerated draws the run must be
+    restarted behind the event exactly as with host draws: bookkeeping, both streams and the vectors against the
+    oracle.  psi is escalated so that the perturbation reaches the leading digits of H (a candidate computed from the
+    wrong stream position would differ visibly)."""
+    import random
+    import snapshot
+    import scenarios
+    from oracle import maus_oracle as orc
+    from adaptive_matrix_solver_amd.engine import DeviceEngine
+    from adaptive_matrix_solver_amd.solver import ProblemType, SolutionCandidate
+    n, P = 40, 8
+    A = scenarios.ginibre(n, 40, 1.0) * 1e13
+    strat = {"overall_psi_aggression_factor": 1e31, "max_psi_retries": 25, "current_convergence_threshold": 1e-8,
+             "convergence_tolerance": 1e-8}                      # psi = 1e11: 1 % of the entries
+    hot = (2, 5)
+    orc.seed_all(77)
+    oc = [orc.new_candidate(A, orc.EIGENVALUE, n) for _ in range(P)]
+    know_o = {"local_solver_preference": orc.DIRECT, "is_sparse_problem": False, "is_hermitian": False}
+    ref = []
+    for it in range(2):
+        for k, c in enumerate(oc):
+            if it == 0 and k in hot:
+                c.alpha = np.complex128(1.0)
+            orc.candidate_step(c, A, None, strat, know_o)
+        ref.append([(c.state, c.stuck, c.retries, c.resets, complex(c.lam), c.v.copy(), c.resid) for c in oc] + [snapshot.rng_digest()])
+    np.random.seed(77); random.seed(77); SolutionCandidate._candidate_id_counter = 0
+    eng = DeviceEngine(pert_mode=pert_mode)
+    pc = [SolutionCandidate(A, ProblemType.EIGENVALUE, n, engine=eng) for _ in range(P)]
+    know = {"local_solver_preference": "direct_solve", "is_sparse_problem": False, "is_hermitian": False}
+    for it in range(2):
+        if it == 0:
+            for k in hot:
+                pc[k].alpha_local_step = np.complex128(1.0)
+        eng.step(pc, A, None, strat, know)
+        for k, c in enumerate(pc):
+            r = ref[it][k]
+            assert (c.state.value, c.stuck_counter, c.local_psi_retries_needed, c.num_resets) == r[:4], (it, k)
+            assert abs(complex(c.lambda_k) - r[4]) <= 1e-9 * abs(r[4]), (it, k)
+            v = np.asarray(c.v_k)
+            assert np.linalg.norm(v - r[5]) <= 1e-7 * np.linalg.norm(r[5]), (it, k, np.linalg.norm(v - r[5]))
+            assert abs(c.residual_k - r[6]) <= 1e-6 * r[6], (it, k)
+        assert snapshot.rng_digest() == ref[it][P], it
+    # the event really happened: the hot candidates hold un-normalised re-initialised vectors after the first step
+    assert all(abs(np.linalg.norm(ref[0][k][5]) - 1.0) > 1e-3 for k in hot)
