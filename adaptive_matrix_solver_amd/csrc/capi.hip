@@ -113,7 +113,7 @@ int maus_ctx_destroy(maus_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
     void* ptrs[] = {c->A, c->b, c->V, c->X, c->U, c->W, c->Y, c->d_slots, c->d_i1, c->d_i2, c->d_c1, c->d_c2, c->d_r1, c->d_r2,
-                    c->H, c->ipiv, c->perm, c->info, c->flags, c->Upert, c->scratch};
+                    c->H, c->ipiv, c->perm, c->mw_sync, c->info, c->flags, c->Upert, c->scratch};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     hist_free(c);
     for (auto& kv : c->mt_taps) if (kv.second.first) (void)hipFree(kv.second.first);
@@ -359,7 +359,8 @@ int maus_matvec_rayleigh(maus_ctx* c, const int* slots, int count, double* num, 
     return 0;
 }
 
-// LU workspace for `want` simultaneous n x n systems.  Sized geometrically and never shrunk: a hipFree + hipMalloc of
+// LU workspace for `want` simultaneous n x n systems.  Sized once (callers announce their population with maus_lu_reserve),
+// grown at most once more -- then to the limit -- and never shrunk: a hipFree + hipMalloc of
 // ~100 GB costs seconds, so a workspace that follows the batch size step by step (the eig population grows by up to 15
 // candidates per iteration, AMS:533-534) would re-allocate inside somebody's timed region.  Callers that know their
 // population announce it with maus_lu_reserve(); batches beyond the workspace run in chunks.
@@ -375,7 +376,7 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     const char* env = getenv("MAUS_LU_BATCH");
     int cap = env ? std::max(1, atoi(env)) : 512;
     int G = round_up(want, 32);
-    if (c->H && c->Hnpad == npad) G = std::max(G, 2 * c->Hg);          // grow at least two-fold
+    if (c->H && c->Hnpad == npad) G = std::max(G, cap);               // a second allocation goes straight to the limit: never a third
     G = std::min(std::min(G, cap), gmax);
     if (c->H && c->Hnpad == npad && c->Hg >= G) return 0;
     HIPCHK(c, hipStreamSynchronize(c->st));
@@ -383,12 +384,14 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     if (c->H) { (void)hipFree(c->H); c->H = nullptr; }
     if (c->ipiv) { (void)hipFree(c->ipiv); c->ipiv = nullptr; }
     if (c->perm) { (void)hipFree(c->perm); c->perm = nullptr; }
+    if (c->mw_sync) { (void)hipFree(c->mw_sync); c->mw_sync = nullptr; }
     if (c->info) { (void)hipFree(c->info); c->info = nullptr; }
     if (c->flags) { (void)hipFree(c->flags); c->flags = nullptr; }
     c->Hg = 0; c->Hbytes = 0;
     HIPCHK(c, hipMalloc((void**)&c->H, per * G));
     HIPCHK(c, hipMalloc((void**)&c->ipiv, sizeof(int) * (size_t)G * npad));
     HIPCHK(c, hipMalloc((void**)&c->perm, sizeof(int) * (size_t)G * npad));
+    HIPCHK(c, hipMalloc((void**)&c->mw_sync, maus_lu_mw_sync_bytes() * (size_t)G));
     HIPCHK(c, hipMalloc((void**)&c->info, sizeof(int) * G));
     HIPCHK(c, hipMalloc((void**)&c->flags, sizeof(int) * G));
     c->Hbytes = per * G; c->Hg = G; c->Hnpad = npad;
@@ -532,7 +535,8 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
         // is bounded -- a streaming kernel beside the zgemm hides ~30 % of its time at best (tools/probe_corun.hip) --
         // and more sub-batches mean smaller, less efficient launches: 1 / 2 / 3 / 4 / 6 streams gave 291 / 290 / 300 /
         // 277 / 279 candidate-steps/s on the driver-shaped run (n=4096, 176-331 solves per step).
-        const int S = std::max(1, std::min(nst, G / 32));
+        static const int min_sub = [] { const char* e = getenv("MAUS_LU_MIN_SUB"); return e ? std::max(1, atoi(e)) : 32; }();
+        const int S = std::max(1, std::min(nst, G / min_sub));
         if (S > 1) HIPCHK(c, hipEventRecord(c->ev_stage, c->st));
         std::vector<LuWs> wss;
         std::vector<int> los;
@@ -543,6 +547,7 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             if (S > 1) HIPCHK(c, hipStreamWaitEvent(st, c->ev_stage, 0));
             LuWs w = make_ws(c, n, g);
             w.H += (long)lo * w.strideH; w.U += (long)lo * w.strideH; w.perm += (long)lo * w.npad; w.ipiv += (long)lo * w.npad; w.info += lo; w.flags += lo; w.st = st;
+            if (S == 1) w.mw_sync = c->mw_sync;          // the only LU in flight on this device: the panel may spread over several workgroups per matrix
             c->prof_st = st;
             if (pert_mode == MAUS_PERT_MT19937) {
                 if (mt_prepare_and_build(c, w, (const maus_mt_desc*)pert_data, off + lo, g, rhs_mode, lo, sb)) return -1;
@@ -581,6 +586,7 @@ int maus_lu_solve_host(maus_ctx* c, int count, int n, const double* a, const dou
     for (int off = 0; off < count; off += Gmax) {
         const int G = std::min(Gmax, count - off);
         LuWs w = make_ws(c, n, G);
+        w.mw_sync = c->mw_sync;
         HIPCHK(c, hipMemcpyAsync(dA, a + 2 * (size_t)n * n * off, ab * G, hipMemcpyHostToDevice, c->st));
         HIPCHK(c, hipMemcpyAsync(dB, b + 2 * (size_t)n * off, bb * G, hipMemcpyHostToDevice, c->st));
         HIPCHK(c, hipMemsetAsync(c->info, 0, sizeof(int) * G, c->st));

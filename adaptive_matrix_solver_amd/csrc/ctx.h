@@ -16,6 +16,7 @@ void maus_build_h(const LuWs& w, const c128* A, const c128* d_shift, const doubl
                   const c128* X, long ldx, const int* d_slots, const c128* bvec, int pert_mode, const double* d_U);
 void maus_load_h(const LuWs& w, const c128* d_Ain, const c128* d_bin);
 int maus_lu_max_npad();
+size_t maus_lu_mw_sync_bytes();
 void maus_mt_copy_states(hipStream_t st, uint32_t* states, const uint32_t* base, int count);
 void maus_mt_jump(hipStream_t st, uint32_t* states, const int* sel, int nsel, const int* taps, int ntap16);
 int maus_mt_zero_tap();
@@ -60,7 +61,7 @@ struct maus_ctx {
     double *d_r1 = nullptr, *d_r2 = nullptr;
     // LU workspace
     c128* H = nullptr; size_t Hbytes = 0; int Hg = 0; int Hnpad = 0; int ws_allocs = 0;
-    int *ipiv = nullptr, *perm = nullptr, *info = nullptr, *flags = nullptr;
+    int *ipiv = nullptr, *perm = nullptr, *info = nullptr, *flags = nullptr; void* mw_sync = nullptr;
     double* Upert = nullptr; size_t Ubytes = 0;
     // device-side MT19937 regeneration (mtdev.hip)
     // one buffer set per sub-batch stream: the host prepares sub-batch s+1 while the jump / build kernels of sub-batch s

@@ -23,7 +23,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <climits>
-#include <cstdlib>
+#include <algorithm>
+#include <type_traits>
 
 void maus_zgemm_launch(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,
                        const c128* B, long ldb, long sB, c128* C, long ldc, long sC,
@@ -748,6 +749,231 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
     if (tid == 0 && s_info != 0 && info_g[blockIdx.x] == 0) info_g[blockIdx.x] = s_info;
 }
 
+// ---------------------------------------------------------------------------------------
+// Base panel spread over W workgroups per matrix (small batches: with one workgroup per matrix a batch of 32 occupies 32
+// of the 256 CUs and the panel phase is bound by one CU's memory pipeline per matrix).  Workgroup w owns the logical rows
+// [w*RPT*PT, (w+1)*RPT*PT) of the panel and keeps its whole 16-column slice in registers (read once, written once); the
+// pivot search and the exchange of the pivot row go through a small per-matrix area in global memory:
+//   per column a:  every workgroup publishes its best row (|re|+|im|, logical index, physical row, the 16 entries) and,
+//                  if it owns logical row a, that row too; arrives on a monotone counter; waits for all W arrivals; reads
+//                  the W candidates, picks the winner by the izamax rule (max value, lowest logical index) and reads its
+//                  row.  One rendezvous per column.
+// Published words are written and read with agent-scope relaxed atomics (sc1: they bypass the per-CU L1 and are
+// written through the XCD's L2), drained with s_waitcnt before the arrival is counted (MI355X_MICROARCH.md, valid
+// hand-off forms); buffers alternate with the column parity, which is enough because nobody can be two rendezvous ahead.
+// Every wait is bounded: after ~2 s without progress a workgroup raises the abort word, everybody leaves, and the
+// matrix reports info = INT_MIN (internal error) instead of hanging the device.  The launcher only uses this kernel
+// when all G*W workgroups are co-resident by construction (one launch in flight, G*W <= number of CUs).
+// ---------------------------------------------------------------------------------------
+constexpr int MW_MAXW = 8;
+struct MwSync {                         // one per matrix; zeroed before every panel launch
+    unsigned long long cnt;             // arrivals (monotone: column a is complete at (a+1)*W)
+    unsigned long long abort_;          // non-zero: a wait timed out
+    unsigned long long meta[2][MW_MAXW][2];   // [parity][w]: value bits, (logical row << 32 | physical row)
+    unsigned long long aphys[2];              // physical row of logical row a
+    double row[2][MW_MAXW][2 * NBP];          // candidate rows
+    double arow[2][2 * NBP];                  // row a
+};
+
+__device__ __forceinline__ void mw_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long mw_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int RPT>
+__global__ void __launch_bounds__(PT)
+lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long strideH, int j0, int m, int W,
+                   int* __restrict__ ipiv_g, int* __restrict__ perm_g, int npad, int* __restrict__ info_g, MwSync* __restrict__ sync_g)
+{
+    const int w = blockIdx.x, g = blockIdx.y;
+    c128* Hm = Hg + (long)g * strideH + j0;
+    c128* Um = Ug + (long)g * strideH + (long)j0 * ld + j0;
+    int* ipiv = ipiv_g + (long)g * npad + j0;
+    int* perm = perm_g + (long)g * npad + j0;
+    MwSync* sy = sync_g + g;
+
+    __shared__ double s_val[PT / 64];
+    __shared__ int s_idx[PT / 64];
+    __shared__ c128 s_row[NBP];          // this workgroup's candidate row, then the winner's row
+    __shared__ c128 s_arow[NBP];         // logical row a (published by its owner), then the displaced row
+    __shared__ int s_phys[2];            // [0] candidate / winner physical row, [1] physical row of logical row a
+    __shared__ unsigned long long s_meta[MW_MAXW][2];
+    __shared__ int s_abort;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rbase = w * RPT * PT;
+    if (tid == 0) s_abort = 0;
+    c128 R[RPT][NBP];
+    int pr[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = rbase + tid + k * PT;
+        pr[k] = (r < m) ? perm[r] : 0;
+        if (r < m) {
+            const c128* row = Hm + (long)pr[k] * ld;
+#pragma unroll
+            for (int c = 0; c < NBP; ++c) R[k][c] = row[c];
+        }
+    }
+    int my_info = 0;
+    bool aborted = false;         // workgroup-uniform: a rendezvous timed out (here or in a sibling workgroup)
+    __syncthreads();
+
+    // one instantiation per column (R is indexed by the column, so `a` must be a compile-time constant; a 16-fold
+    // `#pragma unroll` of this body exceeds the unroller's size limit); after an abort the remaining steps are skipped
+    auto step = [&](auto AC) {
+      constexpr int a = decltype(AC)::value;
+      if (!aborted) {
+        const int par = a & 1;
+        // ---- local candidate: max |re|+|im| over own logical rows >= a, first index wins ----
+        double best = -1.0; int bidx = INT_MAX;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = rbase + tid + k * PT;
+            if (r < m && r >= a) {
+                double v = cabs1(R[k][a]);
+                if (v > best) { best = v; bidx = r; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            double ov = __shfl_xor(best, o, 64);
+            int oi = __shfl_xor(bidx, o, 64);
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        }
+        if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
+        __syncthreads();
+        best = s_val[0]; bidx = s_idx[0];
+#pragma unroll
+        for (int q = 1; q < PT / 64; ++q) {
+            double ov = s_val[q]; int oi = s_idx[q];
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        }
+        const bool own_a = (w == 0);                 // logical rows 0..15 belong to the first workgroup
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = rbase + tid + k * PT;
+            if (r == bidx) {
+#pragma unroll
+                for (int c = 0; c < NBP; ++c) s_row[c] = R[k][c];
+                s_phys[0] = pr[k];
+            }
+            if (r == a) {
+#pragma unroll
+                for (int c = 0; c < NBP; ++c) s_arow[c] = R[k][c];
+                s_phys[1] = pr[k];
+            }
+        }
+        __syncthreads();
+        // ---- publish (wave 0: candidate, wave 1: row a), drain, arrive ----
+        if (wave == 0) {
+            if (lane < 2 * NBP) mw_store((unsigned long long*)&sy->row[par][w][lane], __double_as_longlong(((const double*)s_row)[lane]));
+            if (lane == 32) mw_store(&sy->meta[par][w][0], (unsigned long long)__double_as_longlong(best));
+            if (lane == 33) mw_store(&sy->meta[par][w][1], ((unsigned long long)(unsigned)bidx << 32) | (unsigned)(bidx == INT_MAX ? 0 : s_phys[0]));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (wave == 1 && own_a) {
+            if (lane < 2 * NBP) mw_store((unsigned long long*)&sy->arow[par][lane], __double_as_longlong(((const double*)s_arow)[lane]));
+            if (lane == 32) mw_store(&sy->aphys[par], (unsigned long long)(unsigned)s_phys[1]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&sy->cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long target = (unsigned long long)(a + 1) * W;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+            int spins = 0;
+            while (mw_load(&sy->cnt) < target) {
+                if (mw_load(&sy->abort_)) { s_abort = 1; break; }
+                if ((++spins & 1023) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+                    mw_store(&sy->abort_, 1ull); s_abort = 1; break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        aborted = (s_abort != 0);
+      }
+      if (!aborted) {
+        const int par = a & 1;
+        const bool own_a = (w == 0);
+        // ---- winner by the izamax rule over the W candidates ----
+        if (tid < 2 * W) s_meta[tid >> 1][tid & 1] = mw_load(&sy->meta[par][tid >> 1][tid & 1]);
+        __syncthreads();
+        double gv = -1.0; int gp = INT_MAX, gw = 0, gphys = 0;
+        for (int q = 0; q < W; ++q) {
+            const double v = __longlong_as_double((long long)s_meta[q][0]);
+            const int idx = (int)(s_meta[q][1] >> 32);
+            if (idx != INT_MAX && (v > gv || (v == gv && idx < gp))) { gv = v; gp = idx; gw = q; gphys = (int)(unsigned)(s_meta[q][1] & 0xffffffffull); }
+        }
+        const bool none = (gp == INT_MAX);              // all-NaN column: no interchange (input flagged non-finite)
+        const int p = none ? a : gp;
+        __syncthreads();                                // s_row / s_arow are rewritten below
+        if (wave == 0) {
+            if (lane < 2 * NBP) {
+                const unsigned long long* src = none ? (const unsigned long long*)&sy->arow[par][lane] : (const unsigned long long*)&sy->row[par][gw][lane];
+                ((double*)s_row)[lane] = __longlong_as_double((long long)mw_load(src));
+            }
+        } else if (wave == 1) {
+            if (lane < 2 * NBP) ((double*)s_arow)[lane] = __longlong_as_double((long long)mw_load((const unsigned long long*)&sy->arow[par][lane]));
+            if (lane == 32) s_phys[1] = (int)(unsigned)mw_load(&sy->aphys[par]);
+        }
+        if (tid == 0) s_phys[0] = none ? -1 : gphys;
+        __syncthreads();
+        if (none && tid == 0) s_phys[0] = s_phys[1];
+        // ---- the interchange: the owners of logical rows a and p exchange register rows and physical rows ----
+        if (p != a) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = rbase + tid + k * PT;
+                if (r == a) {
+#pragma unroll
+                    for (int c = 0; c < NBP; ++c) R[k][c] = s_row[c];
+                    pr[k] = s_phys[0];
+                } else if (r == p) {
+#pragma unroll
+                    for (int c = 0; c < NBP; ++c) R[k][c] = s_arow[c];
+                    pr[k] = s_phys[1];
+                }
+            }
+        }
+        const c128 pv = s_row[a];
+        const bool zero_piv = (pv.x == 0.0 && pv.y == 0.0);
+        if (zero_piv && my_info == 0) my_info = j0 + a + 1;              // LAPACK info (1-based)
+        if (own_a) {
+            if (tid == 0) ipiv[a] = j0 + p;
+            if (tid < NBP && tid >= a) Um[(long)a * ld + tid] = s_row[tid];       // row a of U inside the panel
+        }
+        const c128 rinv = zero_piv ? cmake(1.0, 0.0) : crecip(pv);
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = rbase + tid + k * PT;
+            if (r < m && r > a) {
+                const c128 l = cmul(R[k][a], rinv);
+                R[k][a] = l;
+#pragma unroll
+                for (int c = 0; c < NBP; ++c) if (c > a) cfms(R[k][c], l, s_row[c]);
+            }
+        }
+        __syncthreads();
+      }
+    };
+    static_assert(NBP == 16, "lu_panel_mw_kernel: 16 column steps");
+#define MW_STEP(A) step(std::integral_constant<int, A>{})
+    MW_STEP(0); MW_STEP(1); MW_STEP(2); MW_STEP(3); MW_STEP(4); MW_STEP(5); MW_STEP(6); MW_STEP(7);
+    MW_STEP(8); MW_STEP(9); MW_STEP(10); MW_STEP(11); MW_STEP(12); MW_STEP(13); MW_STEP(14); MW_STEP(15);
+#undef MW_STEP
+    if (aborted) { if (tid == 0 && w == 0) info_g[g] = INT_MIN; return; }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = rbase + tid + k * PT;
+        if (r < m) {
+            c128* row = Hm + (long)pr[k] * ld;
+#pragma unroll
+            for (int c = 0; c < NBP; ++c) row[c] = R[k][c];
+            perm[r] = pr[k];
+        }
+    }
+    if (tid == 0 && w == 0 && my_info != 0 && info_g[g] == 0) info_g[g] = my_info;
+}
+
 // U[j..j+TW, cols] = L11^-1 * H[perm[j..j+TW), cols]: the pivot rows are gathered through perm and their finished U
 // rows written to the logical-order array.
 template <int TW>
@@ -904,6 +1130,26 @@ static void lu_panel(const LuWs& w, int j0) {
 #define PANEL(R) hipLaunchKernelGGL((lu_panel_kernel<R>), grid, block, 0, w.st, w.H, w.ldh, w.strideH, j0, m, w.ipiv, w.npad, w.info, dbg)
 #define PANEL_LL(R, W) hipLaunchKernelGGL((lu_panel_ll_kernel<R, W>), grid, block, 0, w.st, w.H, w.ldh, w.strideH, j0, m, w.ipiv, w.npad, w.info)
 #define PANEL_IP(R, W) hipLaunchKernelGGL((lu_panel_ip_kernel<R, W>), grid, block, 0, w.st, w.H, w.U, w.ldh, w.strideH, j0, m, w.ipiv, w.perm, w.npad, w.info)
+    // Small batches: several workgroups per matrix (lu_panel_mw_kernel).  Only when the caller guarantees that this is the
+    // only LU in flight on the device (w.mw_sync set) and all G*W workgroups fit on the chip at once -- the workgroups of a
+    // matrix wait for each other.
+    static const int mw_on = [] { const char* e = getenv("MAUS_PANEL_MW"); return e ? atoi(e) : 1; }();
+    if (lu_implicit() && mw_on && w.mw_sync && m >= 1024) {
+        static const int ncu = [] { int v = 0; int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+        auto p2floor = [](int x) { int p = 1; while (2 * p <= x) p *= 2; return p; };
+        auto p2ceil = [](int x) { int p = 1; while (p < x) p *= 2; return p; };
+        const int wmin = p2ceil((m + 2 * PT - 1) / (2 * PT));
+        const int wmax = std::min(p2floor(std::max(1, ncu / std::max(1, w.G))), MW_MAXW);
+        const int W = std::max(wmin, std::min(wmax, p2floor(m / 256)));
+        if (W >= 2 && W <= wmax) {
+            (void)hipMemsetAsync(w.mw_sync, 0, sizeof(MwSync) * (size_t)w.G, w.st);
+            const int rpt1 = (m + W * PT - 1) / (W * PT);
+            if (rpt1 <= 1) hipLaunchKernelGGL((lu_panel_mw_kernel<1>), dim3(W, w.G), block, 0, w.st, w.H, w.U, w.ldh, w.strideH, j0, m, W, w.ipiv, w.perm, w.npad, w.info, (MwSync*)w.mw_sync);
+            else hipLaunchKernelGGL((lu_panel_mw_kernel<2>), dim3(W, w.G), block, 0, w.st, w.H, w.U, w.ldh, w.strideH, j0, m, W, w.ipiv, w.perm, w.npad, w.info, (MwSync*)w.mw_sync);
+            prof(w, KC_PANEL, 1, 8.0 * m * NBP * NBP / 2 * w.G, 16.0 * m * NBP * 2 * w.G);
+            return;
+        }
+    }
     if (lu_implicit()) {
         if (rpt <= 1) PANEL_IP(1, 4); else if (rpt <= 2) PANEL_IP(2, 4); else if (rpt <= 4) PANEL_IP(4, 4);
         else if (rpt <= 8) PANEL_IP(8, 4); else PANEL_IP(16, 2);
@@ -931,7 +1177,8 @@ static void lu_recurse(const LuWs& w, int j0, int wd) {
 }
 
 // Maximum rows the base panel can own (8 rows per thread x 512 threads)
-int maus_lu_max_npad() { return PT * 16; }     // 16 rows per thread in the 2-column panel variant
+int maus_lu_max_npad() { return PT * 16; }
+size_t maus_lu_mw_sync_bytes() { return sizeof(MwSync); }     // 16 rows per thread in the 2-column panel variant
 
 // Factor all G matrices in the workspace and carry the augmented column through (L y = P b).
 void maus_lu_factor(const LuWs& w, int nbo) {

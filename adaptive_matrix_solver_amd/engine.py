@@ -573,10 +573,12 @@ class DeviceEngine:
         base_psi = PSI_EPSILON_BASE * aggr                              # AMS:224
         pert = self._pert(n)
         words = 4 * n * n                                               # MT19937 words per dense attempt
-        # LU workspace sized once for this rank's share of the population plus the growth of the next iterations
-        # (<= 15 spawns each, AMS:533-534): it must never be re-allocated inside a step (tens of GB, seconds)
-        share = -(-len(cands) // (self.comm.world if self.comm is not None else 1))
-        self.ctx.lu_reserve(n, max(2 * share, share + 64))
+        # LU workspace sized once for this rank's share of the population plus the growth of the next ~20 iterations
+        # (<= 15 spawns each whatever the population, AMS:533-534): it must not be re-allocated inside somebody's timed
+        # step (freeing and mapping ~100 GB takes seconds; HBM is otherwise idle)
+        world = self.comm.world if self.comm is not None else 1
+        share = -(-len(cands) // world)
+        self.ctx.lu_reserve(n, max(2 * share, share + -(-320 // world)))
 
         i = 0
         while i < len(cands):

@@ -122,7 +122,7 @@ int maus_shifted_lu_solve(maus_ctx* ctx, const int* slots, int count, const doub
 /* Size the LU workspace ONCE for up to `count` simultaneous n x n systems (the reference's sla.solve allocates its
  * copy of H per call, AMS:59; here H_k of a whole batch are device-resident, 270 MB each at n = 4096, and re-allocating
  * ~100 GB costs seconds).  Capped by 80 % of the free HBM and MAUS_LU_BATCH (default 512); larger batches run in
- * chunks.  The workspace never shrinks and otherwise grows at least two-fold on demand.  capacity_out (may be NULL):
+ * chunks.  The workspace never shrinks; a batch beyond it makes it grow once, to the limit.  capacity_out (may be NULL):
  * matrices the workspace holds after the call. */
 int maus_lu_reserve(maus_ctx* ctx, int n, int count, int* capacity_out);
 
