@@ -783,11 +783,13 @@ __global__ void __launch_bounds__(PT)
 lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long strideH, int j0, int m, int W,
                    int* __restrict__ ipiv_g, int* __restrict__ perm_g, int npad, int* __restrict__ info_g, MwSync* __restrict__ sync_g)
 {
-    const int w = blockIdx.x, g = blockIdx.y;
+    // blockIdx.x = matrix, blockIdx.y = row chunk: workgroups are dealt round-robin over the 8 XCDs by linear id, so with a
+    // batch that is a multiple of 8 the W workgroups of one matrix share an XCD -- and its L2 -- (speed only)
+    const int w = blockIdx.y, g = blockIdx.x;
     c128* Hm = Hg + (long)g * strideH + j0;
     c128* Um = Ug + (long)g * strideH + (long)j0 * ld + j0;
     int* ipiv = ipiv_g + (long)g * npad + j0;
-    int* perm = perm_g + (long)g * npad + j0;
+    int* perm = perm_g + (long)g * npad + j0;                     // perm[r]: physical row of panel-local logical row r
     MwSync* sy = sync_g + g;
 
     __shared__ double s_val[PT / 64];
@@ -796,6 +798,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
     __shared__ c128 s_arow[NBP];         // logical row a (published by its owner), then the displaced row
     __shared__ int s_phys[2];            // [0] candidate / winner physical row, [1] physical row of logical row a
     __shared__ unsigned long long s_meta[MW_MAXW][2];
+    __shared__ double s_all[MW_MAXW][2 * NBP];       // every workgroup's candidate row
     __shared__ int s_abort;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -894,8 +897,19 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
       if (!aborted) {
         const int par = a & 1;
         const bool own_a = (w == 0);
-        // ---- winner by the izamax rule over the W candidates ----
-        if (tid < 2 * W) s_meta[tid >> 1][tid & 1] = mw_load(&sy->meta[par][tid >> 1][tid & 1]);
+        // ---- one read phase: the W metas, the W candidate rows and row a; the winner (izamax rule: max value, lowest
+        //      logical index) is then picked out of LDS ----
+        {
+            const int nmeta = 2 * W, nrow = 2 * NBP * W, narow = 2 * NBP;
+            for (int e = tid; e < nmeta + nrow + narow + 1; e += PT) {
+                if (e < nmeta) s_meta[e >> 1][e & 1] = mw_load(&sy->meta[par][e >> 1][e & 1]);
+                else if (e < nmeta + nrow) { const int q = (e - nmeta) / (2 * NBP), i = (e - nmeta) % (2 * NBP);
+                                             s_all[q][i] = __longlong_as_double((long long)mw_load((const unsigned long long*)&sy->row[par][q][i])); }
+                else if (e < nmeta + nrow + narow) { const int i = e - nmeta - nrow;
+                                                     ((double*)s_arow)[i] = __longlong_as_double((long long)mw_load((const unsigned long long*)&sy->arow[par][i])); }
+                else s_phys[1] = (int)(unsigned)mw_load(&sy->aphys[par]);
+            }
+        }
         __syncthreads();
         double gv = -1.0; int gp = INT_MAX, gw = 0, gphys = 0;
         for (int q = 0; q < W; ++q) {
@@ -905,19 +919,9 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         }
         const bool none = (gp == INT_MAX);              // all-NaN column: no interchange (input flagged non-finite)
         const int p = none ? a : gp;
-        __syncthreads();                                // s_row / s_arow are rewritten below
-        if (wave == 0) {
-            if (lane < 2 * NBP) {
-                const unsigned long long* src = none ? (const unsigned long long*)&sy->arow[par][lane] : (const unsigned long long*)&sy->row[par][gw][lane];
-                ((double*)s_row)[lane] = __longlong_as_double((long long)mw_load(src));
-            }
-        } else if (wave == 1) {
-            if (lane < 2 * NBP) ((double*)s_arow)[lane] = __longlong_as_double((long long)mw_load((const unsigned long long*)&sy->arow[par][lane]));
-            if (lane == 32) s_phys[1] = (int)(unsigned)mw_load(&sy->aphys[par]);
-        }
-        if (tid == 0) s_phys[0] = none ? -1 : gphys;
+        if (tid < 2 * NBP) ((double*)s_row)[tid] = none ? ((const double*)s_arow)[tid] : s_all[gw][tid];
+        if (tid == 0) s_phys[0] = none ? s_phys[1] : gphys;
         __syncthreads();
-        if (none && tid == 0) s_phys[0] = s_phys[1];
         // ---- the interchange: the owners of logical rows a and p exchange register rows and physical rows ----
         if (p != a) {
 #pragma unroll
@@ -1144,8 +1148,8 @@ static void lu_panel(const LuWs& w, int j0) {
         if (W >= 2 && W <= wmax) {
             (void)hipMemsetAsync(w.mw_sync, 0, sizeof(MwSync) * (size_t)w.G, w.st);
             const int rpt1 = (m + W * PT - 1) / (W * PT);
-            if (rpt1 <= 1) hipLaunchKernelGGL((lu_panel_mw_kernel<1>), dim3(W, w.G), block, 0, w.st, w.H, w.U, w.ldh, w.strideH, j0, m, W, w.ipiv, w.perm, w.npad, w.info, (MwSync*)w.mw_sync);
-            else hipLaunchKernelGGL((lu_panel_mw_kernel<2>), dim3(W, w.G), block, 0, w.st, w.H, w.U, w.ldh, w.strideH, j0, m, W, w.ipiv, w.perm, w.npad, w.info, (MwSync*)w.mw_sync);
+            if (rpt1 <= 1) hipLaunchKernelGGL((lu_panel_mw_kernel<1>), dim3(w.G, W), block, 0, w.st, w.H, w.U, w.ldh, w.strideH, j0, m, W, w.ipiv, w.perm, w.npad, w.info, (MwSync*)w.mw_sync);
+            else hipLaunchKernelGGL((lu_panel_mw_kernel<2>), dim3(w.G, W), block, 0, w.st, w.H, w.U, w.ldh, w.strideH, j0, m, W, w.ipiv, w.perm, w.npad, w.info, (MwSync*)w.mw_sync);
             prof(w, KC_PANEL, 1, 8.0 * m * NBP * NBP / 2 * w.G, 16.0 * m * NBP * 2 * w.G);
             return;
         }

@@ -71,7 +71,7 @@ def init_from_env(backend: str | None = None):
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and os.environ.get("MAUS_FORCE_COMM", "0") != "1":     # MAUS_FORCE_COMM=1: a one-rank group (RCCL smoke test)
         return None
     if not dist.is_initialized():
         if backend is None:

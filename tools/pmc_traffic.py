@@ -22,7 +22,7 @@ trace = [tuple(int(x) for x in line.split()) for line in open(trace_path) if lin
 
 
 def klass(name):
-    for key in ("zgemm", "lu_panel", "laswp", "trsm", "build_h", "backsolve", "mt_jump"):
+    for key in ("zgemm", "lu_panel", "laswp", "trsm", "build_h", "backsolve", "mt_jump", "init_perm"):
         if key in name:
             return key
     return "other"
@@ -63,7 +63,8 @@ for k, cs in acc.items():
         per_class[k] = {"launches": cs["FETCH_SIZE"][0], "fetch_bytes": cs["FETCH_SIZE"][1] * 1024.0 * 2.0,
                         "write_bytes": cs["WRITE_SIZE"][1] * 1024.0}
         per_class[k]["hbm_bytes"] = per_class[k]["fetch_bytes"] + per_class[k]["write_bytes"]
-json.dump({"unit": "bytes per bench step (one 271-solve sweep, MAUS_LU_STREAMS=1)", "classes": per_class,
+matrices = max((t[3] for t in trace), default=0)
+json.dump({"unit": f"bytes per bench step (one sweep of {matrices} solves, MAUS_LU_STREAMS=1)", "matrices": matrices, "classes": per_class,
            "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950), WRITE_SIZE as reported; separate --pmc passes"},
           open(os.path.join(root, "gpurun_out", "pmc_traffic_per_kernel.json"), "w"), indent=1)
 for k, cs in acc.items():
@@ -75,9 +76,9 @@ for k, cs in acc.items():
 
 if "FETCH_SIZE" in big and "WRITE_SIZE" in big:
     f, w = big["FETCH_SIZE"], big["WRITE_SIZE"]
-    out = {"kernel": "zgemm_kernel<64,32,16,3M>, K>=256 launches of the LU trailing updates",
+    out = {"kernel": "zgemm_kernel<64,32,16,3M>, K>=256 launches of the LU trailing updates", "matrices": matrices,
            "command": "MAUS_LU_STREAMS=1 MAUS_LU_TRACE=<file> rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace "
-                      "-- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --kernel-events off",
+                      "-- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-isolated --no-small-batch --kernel-events off",
            "launches": f[0], "fetch_bytes_per_launch": f[1] * 1024.0 * 2.0 / f[0], "write_bytes_per_launch": w[1] * 1024.0 / w[0],
            "algorithmic_bytes_per_launch": f[2] / f[0],
            "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); WRITE_SIZE as reported; KB units"}
