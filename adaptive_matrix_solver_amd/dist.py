@@ -77,6 +77,14 @@ def init_from_env(backend: str | None = None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
+            # torch's wheel bundles its own HIP runtime under the same soname as /opt/rocm's (libamdhip64.so.7).  Loaded
+            # first, it also serves libmaus_hip.so; loaded second it finds the device already held by the other runtime
+            # ("No HIP GPUs are available", tools/probe_torch_hip_order.py).  So: process group before the first context.
+            if not torch.cuda.is_available():
+                from . import _cabi
+                hint = (" -- libmaus_hip.so was loaded before torch initialised its HIP runtime: call dist.init_from_env() "
+                        "before creating a Context / MAUS_Solver") if _cabi._lib is not None else ""
+                raise RuntimeError("backend 'nccl' needs torch.cuda, which sees no GPU" + hint)
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group(backend=backend)
     return PopulationComm()

@@ -117,6 +117,11 @@ def main():
                     help="HIP-event bracketing of kernel launches in the timed region: every K>=256 zgemm launch (default), "
                          "every launch of every kernel (costs 3-5 %% of throughput), or none")
     ap.add_argument("--cpu-budget", type=float, default=40.0)
+    ap.add_argument("--skip-diagnosis", action="store_true",
+                    help="profiling aid: construct the solver with the known start-up diagnostics of the metric's matrix "
+                         "(dense, non-Hermitian, 'Stable') instead of running the condition estimator, whose ten "
+                         "single-matrix LUs would otherwise be mixed into rocprofv3's per-kernel averages; the timed loop "
+                         "bodies are the same")
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks, form the process group, all-gather the rank ids, print {n_gpus} and exit "
                          "without touching a GPU (tests/test_dist_gloo.py checks the --gpus N self-launch with it)")
@@ -163,7 +168,11 @@ def main():
                            engine=engine, diag_info=diag)
 
     t_build = time.perf_counter()
-    solver = build(P)
+    diag0 = None
+    if args.skip_diagnosis:
+        diag0 = {"is_hermitian": False, "is_complex_symmetric": False, "is_sparse_init": False, "condition_number": 1.0e4,
+                 "is_singular": False, "condition_number_is_estimate": True, "note": "--skip-diagnosis placeholder"}
+    solver = build(P, diag=diag0)
     t_build = time.perf_counter() - t_build
     ctx = solver.engine.ctx
     info = ctx.device_info()

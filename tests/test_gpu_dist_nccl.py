@@ -34,10 +34,10 @@ def run(comm):
                     for c in s.candidates] + [snapshot.rng_digest()])
     return out
 
-ref = run(None)
 from adaptive_matrix_solver_amd import dist as mdist
-comm = mdist.init_from_env("nccl")
+comm = mdist.init_from_env("nccl")           # before the first device context: torch's HIP runtime must load first
 assert comm is not None and comm.on_device and comm.dist.get_backend() == "nccl"
+ref = run(None)
 got = run(comm)
 import torch
 t = torch.tensor([1.5], dtype=torch.float64, device=comm.device)
