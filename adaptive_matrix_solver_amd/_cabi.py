@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmaus_hip.so")
 # every symbol include/maus_hip.h declares (tests/test_cabi_symbols.py checks the list against the header)
 SYMBOLS = [
     "maus_ctx_create", "maus_ctx_destroy", "maus_last_error", "maus_device_info", "maus_abi_version",
-    "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get", "maus_pop_copy", "maus_hist_append", "maus_hist_get", "maus_hist_clear",
+    "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get", "maus_pop_copy", "maus_pop_device_ptr", "maus_hist_append", "maus_hist_get", "maus_hist_clear",
     "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_lu_reserve", "maus_lu_workspace_allocs", "maus_relax_normalise", "maus_residual",
     "maus_svd_power_step", "maus_set_eigvecs", "maus_herm_match", "maus_gmres", "maus_gmres_pert", "maus_jacobi_check",
     "maus_profile_union_ms", "maus_gram", "maus_zgemm_host", "maus_zgemm_bench", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
@@ -69,6 +69,7 @@ def load_library():
         "maus_pop_put": ([vp, C.c_int, vp, C.c_int, vp, C.c_int], C.c_int),
         "maus_pop_get": ([vp, C.c_int, vp, C.c_int, vp, C.c_int], C.c_int),
         "maus_pop_copy": ([vp, C.c_int, C.c_int, vp, C.c_int], C.c_int),
+        "maus_pop_device_ptr": ([vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_long), ip], C.c_int),
         "maus_hist_append": ([vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_int64)], C.c_int),
         "maus_hist_get": ([vp, vp, C.c_int, C.c_int, vp], C.c_int),
         "maus_hist_clear": ([vp], C.c_int),
@@ -224,6 +225,12 @@ class Context:
     def pop_copy(self, which_dst, which_src, slots):
         s = self._slots(slots)
         self._ck(self.lib.maus_pop_copy(self.h, int(which_dst), int(which_src), _ptr(s), s.shape[0]), "maus_pop_copy")
+
+    def pop_device_ptr(self, which):
+        """(device address, leading dimension in complex elements, capacity in rows) of a population array."""
+        ptr, ld, cap = C.c_void_p(), C.c_long(), C.c_int()
+        self._ck(self.lib.maus_pop_device_ptr(self.h, int(which), C.byref(ptr), C.byref(ld), C.byref(cap)), "maus_pop_device_ptr")
+        return int(ptr.value), int(ld.value), int(cap.value)
 
     def hist_append(self, which, slots, length) -> int:
         """Append rows `slots` of population array `which` to the device history; returns the first row's index."""

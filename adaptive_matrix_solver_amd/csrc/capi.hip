@@ -251,6 +251,16 @@ __global__ void copy_rows_kernel(c128* __restrict__ dst, const c128* __restrict_
     for (int k = threadIdx.x; k < len; k += blockDim.x) dst[o + k] = src[o + k];
 }
 
+int maus_pop_device_ptr(maus_ctx* c, int which, void** ptr_out, long* ld_out, int* capacity_out) {
+    c128* P = pop_array(c, which);
+    if (!P || !ptr_out) FAIL(c, "maus_pop_device_ptr: population not reserved / bad arguments");
+    HIPCHK(c, hipStreamSynchronize(c->st));          // the caller is about to touch the rows from another stream
+    *ptr_out = (void*)P;
+    if (ld_out) *ld_out = c->ldp;
+    if (capacity_out) *capacity_out = c->cap;
+    return 0;
+}
+
 int maus_pop_copy(maus_ctx* c, int which_dst, int which_src, const int* slots, int count) {
     c128* D = pop_array(c, which_dst); c128* S = pop_array(c, which_src);
     if (!D || !S || D == S) FAIL(c, "maus_pop_copy: population not reserved / bad array ids");

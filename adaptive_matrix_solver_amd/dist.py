@@ -62,6 +62,36 @@ class PopulationComm:
         full = out.cpu().numpy().reshape(self.world, cmax, width)
         return np.concatenate([full[r, : counts[r]] for r in range(self.world)], axis=0)
 
+    # ---- candidate rows, device to device ---------------------------------------------------------
+    class _DevArray:
+        """__cuda_array_interface__ view of a population array of the library's context (float64 pairs)."""
+        def __init__(self, ptr, rows, cols):
+            self.__cuda_array_interface__ = {"shape": (rows, cols), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+    def sync_rows_device(self, ctx, which: int, slots_by_rank, length: int) -> None:
+        """After a sharded step every rank holds fresh rows only for its own candidates.  All-gather them over RCCL straight
+        out of / into the contexts' population arrays (one gather kernel, one all-gather, one scatter kernel) -- no host
+        bounce.  slots_by_rank[r] = the slots rank r updated, in list order (identical on every rank)."""
+        torch = self.torch
+        ptr, ld, cap = ctx.pop_device_ptr(which)                 # joins the context's stream
+        X = torch.as_tensor(PopulationComm._DevArray(ptr, cap, 2 * ld), device=self.device)
+        cmax = max((len(s) for s in slots_by_rank), default=0)
+        if cmax == 0:
+            return
+        w = 2 * length
+        send = torch.zeros((cmax, w), dtype=torch.float64, device=self.device)
+        mine = slots_by_rank[self.rank]
+        if len(mine):
+            send[: len(mine)] = X[torch.as_tensor(mine, dtype=torch.long, device=self.device), :w]
+        out = torch.empty((self.world * cmax, w), dtype=torch.float64, device=self.device)
+        self.dist.all_gather_into_tensor(out, send)
+        self.collectives += 1
+        self.bytes_gathered += out.numel() * 8
+        for r, sl in enumerate(slots_by_rank):
+            if len(sl):                                           # own rows too: the same bytes, one code path
+                X[torch.as_tensor(sl, dtype=torch.long, device=self.device), :w] = out[r * cmax: r * cmax + len(sl)]
+        torch.cuda.current_stream(self.device).synchronize()     # the library's stream may read the rows from here on
+
     def barrier(self):
         self.dist.barrier()
 

@@ -21,6 +21,7 @@ No CPU fallback: every matrix-sized operation goes through the C ABI.
 """
 from __future__ import annotations
 
+import os
 import random as _pyrandom
 import weakref
 
@@ -406,6 +407,12 @@ class DeviceEngine:
         arrays = [(POP_X, cands[0]._len_v())]
         if cands[0].problem_type == ProblemType.SVD:
             arrays.append((POP_U, cands[0].M_rows))
+        if self.comm.on_device and os.environ.get("MAUS_DIST_DEVICE_ROWS", "1") != "0":
+            # RCCL straight between the population arrays (dist.PopulationComm.sync_rows_device)
+            by_rank = [[c._slot for c in cands if self._owner.get(id(c), 0) == r] for r in range(self.comm.world)]
+            for which, length in arrays:
+                self.comm.sync_rows_device(self.ctx, which, by_rank, length)
+            return
         mine_set = set(mine)
         others = [k for k in range(len(cands)) if k not in mine_set]
         for which, length in arrays:

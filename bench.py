@@ -196,6 +196,18 @@ def main():
         scale = max(1, round(256 / per_rank))
         os.environ["MAUS_PROF_STRIDE"] = f"{scale},0"
     mode = {"sampled": 2, "all": 1, "off": 0}[args.kernel_events]
+    # wall time inside maus_shifted_lu_solve per loop body (the rest of a loop body: Rayleigh / relax / residual phases,
+    # the host's RNG-event replay and population bookkeeping, collectives)
+    lu_wall = [0.0]
+    _lu = ctx.shifted_lu_solve
+
+    def _timed_lu(*a, **k):
+        t = time.perf_counter()
+        try:
+            return _lu(*a, **k)
+        finally:
+            lu_wall[0] += time.perf_counter() - t
+    ctx.shifted_lu_solve = _timed_lu
     ctx.profile_enable(mode)
     sync_all()
     t0 = time.perf_counter()
@@ -205,10 +217,11 @@ def main():
     for _ in range(args.steps):
         it += 1
         ts = time.perf_counter()
+        lu_wall[0] = 0.0
         act = solver.loop_body(it)               # ends synchronously: the host fetched every phase's results
         te = time.perf_counter()
         steps_done += act
-        rec = {"ms": round((te - ts) * 1e3, 3), "active": act}
+        rec = {"ms": round((te - ts) * 1e3, 3), "active": act, "lu_call_ms": round(lu_wall[0] * 1e3, 3)}
         if mode:
             z = ctx.profile_read_class(0)        # cumulative since profile_enable
             rec["k256_union_ms"] = round(z["union_ms"] - cum_union, 3)

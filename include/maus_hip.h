@@ -85,6 +85,12 @@ int maus_pop_capacity(maus_ctx* ctx);
 int maus_pop_put(maus_ctx* ctx, int which, const int* slots, int count, const double* host_c128, int len);
 int maus_pop_get(maus_ctx* ctx, int which, const int* slots, int count, double* host_c128, int len);
 
+/* Device address of population array `which` (capacity x ld complex128 elements, row-major) after joining the context's
+ * stream -- for a caller that exchanges candidate rows between GPUs with its own collective library (RCCL through
+ * torch.distributed in dist.py) without bouncing them through the host.  The pointer is invalidated by
+ * maus_pop_reserve / maus_set_matrix with a different vector length. */
+int maus_pop_device_ptr(maus_ctx* ctx, int which, void** ptr_out, long* ld_out, int* capacity_out);
+
 /* Device-side copy of the rows `slots` from population array which_src to which_dst (no host traffic).  Used to
  * snapshot the candidates of a speculative batch before the relaxed update overwrites them, so that a run can be
  * restarted behind an RNG event (E4 tiny-norm re-initialisation, AMS:283) exactly as the sequential reference

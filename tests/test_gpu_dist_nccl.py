@@ -21,24 +21,29 @@ import numpy as np
 import scenarios, snapshot
 from adaptive_matrix_solver_amd.solver import MAUS_Solver, ProblemType, SolutionCandidate
 
-def run(comm):
-    spec = scenarios.TRAJECTORIES["eig64"]
+def run(comm, name="eig64"):
+    spec = scenarios.TRAJECTORIES[name]
     A, b = scenarios.build(spec)
     np.random.seed(spec["seed"]); random.seed(spec["seed"]); SolutionCandidate._candidate_id_counter = 0
-    s = MAUS_Solver(A, ProblemType.EIGENVALUE, initial_num_candidates=spec["P"], global_convergence_tol=spec["tol"],
+    PT = {"eig": ProblemType.EIGENVALUE, "svd": ProblemType.SVD, "lin": ProblemType.SOLVE_LINEAR_SYSTEM}[spec["kind"]]
+    s = MAUS_Solver(A, PT, b_vector=b, initial_num_candidates=spec["P"], global_convergence_tol=spec["tol"],
                     quiet=True, comm=comm, pert_mode="mt19937")
     out = []
     for it in range(4):
         s.loop_body(it + 1)
-        out.append([[c.id, c.state.value, c.stuck_counter, c.local_psi_retries_needed, repr(complex(c.lambda_k)), repr(float(c.residual_k))]
+        lam = (lambda c: c.sigma_k) if spec["kind"] == "svd" else (lambda c: c.lambda_k if spec["kind"] == "eig" else 0.0)
+        out.append([[c.id, c.state.value, c.stuck_counter, c.local_psi_retries_needed, repr(complex(lam(c))), repr(float(c.residual_k))]
                     for c in s.candidates] + [snapshot.rng_digest()])
+    # the rows themselves (they travelled device to device through RCCL in the sharded run)
+    vec = (lambda c: c.right_v_k) if spec["kind"] == "svd" else ((lambda c: c.v_k) if spec["kind"] == "eig" else (lambda c: c.x_k))
+    out.append([np.asarray(vec(c)).tobytes().hex()[:64] for c in s.candidates])
     return out
 
 from adaptive_matrix_solver_amd import dist as mdist
 comm = mdist.init_from_env("nccl")           # before the first device context: torch's HIP runtime must load first
 assert comm is not None and comm.on_device and comm.dist.get_backend() == "nccl"
-ref = run(None)
-got = run(comm)
+ref = [run(None, n) for n in ("eig64", "svd5x4", "lin24")]
+got = [run(comm, n) for n in ("eig64", "svd5x4", "lin24")]
 import torch
 t = torch.tensor([1.5], dtype=torch.float64, device=comm.device)
 comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
@@ -54,4 +59,4 @@ def test_population_comm_over_rccl_world_size_one():
     assert r.returncode == 0, r.stderr[-3000:]
     rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["equal"], "the run through RCCL differs from the single-process run"
-    assert rec["collectives"] >= 4 * 4 and rec["bytes"] > 0 and rec["max"] == 1.5
+    assert rec["collectives"] >= 3 * 4 * 4 and rec["bytes"] > 0 and rec["max"] == 1.5
