@@ -749,6 +749,7 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
     if (tid == 0 && s_info != 0 && info_g[blockIdx.x] == 0) info_g[blockIdx.x] = s_info;
 }
 
+#if MAUS_NBP == 16
 // ---------------------------------------------------------------------------------------
 // Base panel spread over W workgroups per matrix (small batches: with one workgroup per matrix a batch of 32 occupies 32
 // of the 256 CUs and the panel phase is bound by one CU's memory pipeline per matrix).  Workgroup w owns the logical rows
@@ -978,6 +979,8 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
     if (tid == 0 && w == 0 && my_info != 0 && info_g[g] == 0) info_g[g] = my_info;
 }
 
+#endif  // MAUS_NBP == 16
+
 // U[j..j+TW, cols] = L11^-1 * H[perm[j..j+TW), cols]: the pivot rows are gathered through perm and their finished U
 // rows written to the logical-order array.
 template <int TW>
@@ -1137,6 +1140,7 @@ static void lu_panel(const LuWs& w, int j0) {
     // Small batches: several workgroups per matrix (lu_panel_mw_kernel).  Only when the caller guarantees that this is the
     // only LU in flight on the device (w.mw_sync set) and all G*W workgroups fit on the chip at once -- the workgroups of a
     // matrix wait for each other.
+#if MAUS_NBP == 16
     static const int mw_on = [] { const char* e = getenv("MAUS_PANEL_MW"); return e ? atoi(e) : 1; }();
     if (lu_implicit() && mw_on && w.mw_sync && m >= 1024) {
         static const int ncu = [] { int v = 0; int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
@@ -1154,6 +1158,7 @@ static void lu_panel(const LuWs& w, int j0) {
             return;
         }
     }
+#endif
     if (lu_implicit()) {
         if (rpt <= 1) PANEL_IP(1, 4); else if (rpt <= 2) PANEL_IP(2, 4); else if (rpt <= 4) PANEL_IP(4, 4);
         else if (rpt <= 8) PANEL_IP(8, 4); else PANEL_IP(16, 2);
@@ -1182,7 +1187,11 @@ static void lu_recurse(const LuWs& w, int j0, int wd) {
 
 // Maximum rows the base panel can own (8 rows per thread x 512 threads)
 int maus_lu_max_npad() { return PT * 16; }
-size_t maus_lu_mw_sync_bytes() { return sizeof(MwSync); }     // 16 rows per thread in the 2-column panel variant
+#if MAUS_NBP == 16
+size_t maus_lu_mw_sync_bytes() { return sizeof(MwSync); }
+#else
+size_t maus_lu_mw_sync_bytes() { return 64; }
+#endif     // 16 rows per thread in the 2-column panel variant
 
 // Factor all G matrices in the workspace and carry the augmented column through (L y = P b).
 void maus_lu_factor(const LuWs& w, int nbo) {

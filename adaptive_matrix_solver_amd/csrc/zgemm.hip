@@ -25,6 +25,10 @@
 #include "common.h"
 #include <cstdlib>
 
+#ifndef MAUS_WC
+#define MAUS_WC 8
+#endif
+
 namespace {
 
 template <int BM, int BN, int BK, int WM, int WN, int BLAY, bool CONJA, bool CONJB, bool PIPE, int MINW, bool M3 = false>
@@ -297,6 +301,174 @@ zgemm_kernel(int M, int N, int K,
         }
 }
 
+// ---------------------------------------------------------------------------------------
+// 3M zgemm with LDS-DMA staging (plain layout, the LU trailing updates).  Same 64 x 32 workgroup tile, 2 x 2 waves and
+// 32 x 16 wave tile as the register-staged 3M kernel above, but the operand tiles go global -> LDS directly
+// (global_load_lds_dwordx4: no staging VGPRs, no ds_write), in K-steps of 8 through a ring of NST buffers with ONE barrier
+// per step.  Without the 24 staging VGPRs the kernel fits 96 VGPRs, i.e. five workgroups per CU instead of four.
+//
+// An LDS-DMA wave-instruction writes 64 x 16 B contiguously (lane-linear), so the LDS images are linear and any swizzle
+// goes on the per-lane SOURCE address (and, identically, on the fragment read):
+//   A image [64 rows][8 k]  (128 B per row): slot (r, kk) holds A[r][k0 + (kk ^ ((r >> 1) & 7))].  One instruction fills
+//       8 rows (8 lanes = one row = 128 contiguous bytes of global memory).  The fragment read a = A[row = lane&15][k = lane>>4]
+//       then takes 16 rows at a 128-B stride: the row parity selects the bank half and the XOR spreads the 8 rows of equal
+//       parity over the 8 16-B columns -- conflict-free in every 16-lane group the hardware forms.
+//   B image [8 k][32 n]  (512 B per k-row): natural order; the fragment read b = B[k = lane>>4][col = lane&15] is 16
+//       consecutive elements of one row.
+// ---------------------------------------------------------------------------------------
+template <int NST, int MINW, int MB, int NB>
+__global__ void __launch_bounds__(256, MINW)
+zgemm3m_dma_kernel(int M, int N, int K,
+                   const c128* __restrict__ Ag, long lda, long strideA,
+                   const c128* __restrict__ Bg, long ldb, long strideB,
+                   c128* __restrict__ Cg, long ldc, long strideC,
+                   double alpha, int beta, int tiles_n, int nwg,
+                   const int* __restrict__ a_rows, const int* __restrict__ c_rows, long rows_stride)
+{
+    constexpr int WN = 2, BM = 2 * 16 * MB, BN = WN * 16 * NB, BKS = 8;      // 2 x 2 waves, wave tile (16 MB) x (16 NB)
+    constexpr int A_ST = BM * BKS, B_ST = BKS * BN;            // elements per stage
+    constexpr int A_PW = BM / 32;                              // A instructions per wave and stage (8 rows each)
+    constexpr int B_PW = BN / 32;                              // B instructions per wave and stage (64 elements each)
+    constexpr int DMA_PW = A_PW + B_PW;
+    __shared__ c128 smem[NST * (A_ST + B_ST)];
+
+    int bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int WC = MAUS_WC;
+    const int tiles_m = nwg / tiles_n;
+    const int full = tiles_m * WC;
+    int cb = bid / full, rem = bid - cb * full, wl = WC;
+    const int ncb = (tiles_n + WC - 1) / WC;
+    if (cb >= ncb - 1) { cb = ncb - 1; rem = bid - cb * full; wl = tiles_n - cb * WC; }
+    const int tm = rem / wl, tn = cb * WC + (rem - tm * wl);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const long batch = blockIdx.y;
+    const c128* A = Ag + batch * strideA;
+    const c128* B = Bg + batch * strideB;
+    c128* C = Cg + batch * strideC;
+    if (a_rows) a_rows += batch * rows_stride;
+    if (c_rows) c_rows += batch * rows_stride;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+
+    // per-lane DMA sources.  A: wave w issues the 8-row blocks A_PW*w .. ; B: wave w issues the 64-element pieces B_PW*w ..
+    const c128* srcA[A_PW];
+#pragma unroll
+    for (int j = 0; j < A_PW; ++j) {
+        const int r = (A_PW * wave + j) * 8 + (lane >> 3);
+        const int kk = (lane & 7) ^ ((r >> 1) & 7);
+        const int gm = min(m0 + r, M - 1);
+        srcA[j] = A + (long)(a_rows ? a_rows[gm] : gm) * lda + kk;
+    }
+    const c128* srcB[B_PW];
+#pragma unroll
+    for (int j = 0; j < B_PW; ++j) {
+        const int e = (B_PW * wave + j) * 64 + lane;             // element of the [8][BN] image
+        srcB[j] = B + (long)(e / BN) * ldb + min(n0 + (e % BN), N - 1);
+    }
+
+    auto issue = [&](int st, int k0) {
+        c128* As = smem + st * (A_ST + B_ST);
+        c128* Bs = As + A_ST;
+#pragma unroll
+        for (int j = 0; j < A_PW; ++j)
+            __builtin_amdgcn_global_load_lds((const void*)(srcA[j] + k0), (__attribute__((address_space(3))) void*)(As + (A_PW * wave + j) * 64), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j)
+            __builtin_amdgcn_global_load_lds((const void*)(srcB[j] + (long)k0 * ldb), (__attribute__((address_space(3))) void*)(Bs + (B_PW * wave + j) * 64), 16, 0, 0);
+    };
+
+    d4 cre[MB][NB], cim[MB][NB], c3[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { cre[i][j] = (d4){0, 0, 0, 0}; cim[i][j] = (d4){0, 0, 0, 0}; c3[i][j] = (d4){0, 0, 0, 0}; }
+
+    const int nst = K / BKS;                         // K is a multiple of 8 on this path (launcher)
+    // prologue: NST-1 stages in flight
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) if (s < nst) issue(s, s * BKS);
+
+    const int arow0 = wm * 16 * MB + (lane & 15);
+    const int bcol0 = wn * 16 * NB + (lane & 15);
+    const int q = lane >> 4;
+    for (int t = 0; t < nst; ++t) {
+        // stage t has landed once at most NST-2 younger stages (DMA_PW instructions each) are still in flight
+        if (NST >= 3 && t + NST - 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * DMA_PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // everybody's part of stage t is in LDS; everybody has left stage t-1
+        asm volatile("" ::: "memory");
+        if (t + NST - 1 < nst) issue((t + NST - 1) % NST, (t + NST - 1) * BKS);     // into the buffer stage t-1 used
+        const c128* As = smem + (t % NST) * (A_ST + B_ST);
+        const c128* Bs = As + A_ST;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int k = ks * 4 + q;
+            c128 fa[MB], fb[NB];
+            double as[MB], bs[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int r = arow0 + i * 16;
+                fa[i] = As[r * BKS + (k ^ ((r >> 1) & 7))];
+                as[i] = fa[i].x + fa[i].y;
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { fb[j] = Bs[k * BN + bcol0 + j * 16]; bs[j] = fb[j].x + fb[j].y; }
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    cre[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i].x, fb[j].x, cre[i][j], 0, 0, 0);
+                    cim[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i].y, fb[j].y, cim[i][j], 0, 0, 0);
+                    c3[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[i], bs[j], c3[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // epilogue (as in zgemm_kernel)
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int gn = n0 + wn * 16 * NB + j * 16 + (lane & 15);
+            c128 cold[4];
+            long off[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm * 16 * MB + i * 16 + (lane >> 4) + 4 * r;
+                const int cm = min(gm, M - 1), cn = min(gn, N - 1);
+                off[r] = (long)(c_rows ? c_rows[cm] : cm) * ldc + cn;
+                cold[r] = cmake(0.0, 0.0);
+                if (beta) cold[r] = C[off[r]];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm * 16 * MB + i * 16 + (lane >> 4) + 4 * r;
+                if (gm < M && gn < N) {
+                    const double vr = cre[i][j][r] - cim[i][j][r];
+                    const double vi = (c3[i][j][r] - cre[i][j][r]) - cim[i][j][r];
+                    C[off[r]] = cmake(alpha * vr + cold[r].x, alpha * vi + cold[r].y);
+                }
+            }
+        }
+}
+
+template <int NST, int MINW, int MB, int NB>
+void launch_dma(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA, const c128* B, long ldb, long sB,
+                c128* C, long ldc, long sC, double alpha, int beta, int batch, int, bool, bool,
+                const int* a_rows, const int* c_rows, long rows_stride)
+{
+    constexpr int BM = 32 * MB, BN = 32 * NB;
+    int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    int nwg = tiles_m * tiles_n;
+    hipLaunchKernelGGL((zgemm3m_dma_kernel<NST, MINW, MB, NB>), dim3(nwg, batch), dim3(256), 0, st,
+                       M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows, rows_stride);
+}
+
 template <int BM, int BN, int BK, int WM, int WN, bool PIPE, int MINW>
 void launch_cfg(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA, const c128* B, long ldb, long sB,
                 c128* C, long ldc, long sC, double alpha, int beta, int batch, int blay, bool conja, bool conjb,
@@ -358,6 +530,21 @@ void maus_zgemm_launch_rows(hipStream_t st, int M, int N, int K, const c128* A, 
         // problem so that no MFMA runs on padding.
         if (N <= 16) { launch_lu_only<128, 16, 16, 4, 1>(ARGS); return; }
         if (M <= 16) { launch_lu_only<16, 128, 16, 1, 4, false, 3>(ARGS); return; }
+        // K >= 256 (the trailing updates proper, 92 % of the flops): the LDS-DMA staged 3M kernel.  Measured on MI355X
+        // (tools/gemm_k512_check.py, 3584 x 3616 x 512, 136 matrices, 8MNK-equivalent TFLOP/s): 83.6 against 79.2 for the
+        // register-staged kernel below -- without staging registers it fits 87 VGPRs and FIVE workgroups share a CU (six:
+        // 82.6; a ring of three buffers at four per CU: 78.1; 64 x 64 tiles at three / four per CU: 82.1 / 82.2 (spills);
+        // 32 x 64: 82.1).  Same summation order as the register-staged kernel, hence the same bits.  The K = 64 / 128
+        // levels of the recursion do not gain (too few K-steps per tile) and keep the kernel below.  MAUS_GEMM_DMA=0
+        // switches back.
+        static const int dma = [] { const char* e = getenv("MAUS_GEMM_DMA"); return e ? atoi(e) : 1; }();
+        if (use3m && dma && M > 32 && (K % 8) == 0 && K >= 256) {
+            if (dma == 3) launch_dma<3, 4, 2, 1>(ARGS);
+            else if (dma == 43) launch_dma<2, 3, 2, 2>(ARGS);          // 64 x 64 tile, 3 workgroups per CU
+            else if (dma == 12) launch_dma<2, 5, 1, 2>(ARGS);          // 32 x 64 tile
+            else launch_dma<2, 5, 2, 1>(ARGS);
+            return;
+        }
         if (use3m) {
             // 3M complex product: three real MFMA products per complex one (ArBr, AiBi, (Ar+Ai)(Br+Bi))
             // instead of four.  A 32x16 wave tile keeps the three accumulator planes, the fragments and the

@@ -37,7 +37,7 @@ for d in dirs:
         # LU trailing-update launches = zgemm dispatches in plain layout; the population products (BLAY=1 /
         # conjugated) are launched outside the LU and are not in the trace: they use the 64x64 4M kernel with
         # a row gather, which the LU never does, so "zgemm_kernel<64, 64" identifies them
-        lu_rows = [r for r in rows if "zgemm_kernel" in r["Kernel_Name"] and "zgemm_kernel<64, 64" not in r["Kernel_Name"]]
+        lu_rows = [r for r in rows if ("zgemm_kernel" in r["Kernel_Name"] or "zgemm3m_dma_kernel" in r["Kernel_Name"]) and "zgemm_kernel<64, 64" not in r["Kernel_Name"]]
         per_counter = collections.defaultdict(list)
         for r in lu_rows:
             per_counter[r["Counter_Name"]].append(r)
