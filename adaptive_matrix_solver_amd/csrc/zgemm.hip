@@ -402,28 +402,37 @@ zgemm3m_dma_kernel(int M, int N, int K,
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                // everybody's part of stage t is in LDS; everybody has left stage t-1
         asm volatile("" ::: "memory");
-        if (t + NST - 1 < nst) issue((t + NST - 1) % NST, (t + NST - 1) * BKS);     // into the buffer stage t-1 used
         const c128* As = smem + (t % NST) * (A_ST + B_ST);
         const c128* Bs = As + A_ST;
+        // all fragment reads of the stage BEFORE the prefetch is issued: hipcc protects the first ds_read that follows a
+        // global_load_lds it has seen with s_waitcnt vmcnt(0) (possible alias); issued first, the prefetch was waited for
+        // at once (seen in the .s).  Behind the reads, the next ds_read is the one after the next rendezvous.
+        c128 fa[2][MB], fb[2][NB];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int k = ks * 4 + q;
-            c128 fa[MB], fb[NB];
-            double as[MB], bs[NB];
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
                 const int r = arow0 + i * 16;
-                fa[i] = As[r * BKS + (k ^ ((r >> 1) & 7))];
-                as[i] = fa[i].x + fa[i].y;
+                fa[ks][i] = As[r * BKS + (k ^ ((r >> 1) & 7))];
             }
 #pragma unroll
-            for (int j = 0; j < NB; ++j) { fb[j] = Bs[k * BN + bcol0 + j * 16]; bs[j] = fb[j].x + fb[j].y; }
+            for (int j = 0; j < NB; ++j) fb[ks][j] = Bs[k * BN + bcol0 + j * 16];
+        }
+        if (t + NST - 1 < nst) issue((t + NST - 1) % NST, (t + NST - 1) * BKS);     // into the buffer stage t-1 used
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            double as[MB], bs[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) as[i] = fa[ks][i].x + fa[ks][i].y;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bs[j] = fb[ks][j].x + fb[ks][j].y;
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    cre[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i].x, fb[j].x, cre[i][j], 0, 0, 0);
-                    cim[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i].y, fb[j].y, cim[i][j], 0, 0, 0);
+                    cre[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][i].x, fb[ks][j].x, cre[i][j], 0, 0, 0);
+                    cim[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][i].y, fb[ks][j].y, cim[i][j], 0, 0, 0);
                     c3[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[i], bs[j], c3[i][j], 0, 0, 0);
                 }
         }
@@ -540,6 +549,8 @@ void maus_zgemm_launch_rows(hipStream_t st, int M, int N, int K, const c128* A, 
         static const int dma = [] { const char* e = getenv("MAUS_GEMM_DMA"); return e ? atoi(e) : 1; }();
         if (use3m && dma && M > 32 && (K % 8) == 0 && K >= 256) {
             if (dma == 3) launch_dma<3, 4, 2, 1>(ARGS);
+            else if (dma == 44) launch_dma<2, 4, 2, 2>(ARGS);
+            else if (dma == 1 && M >= 1536 && N >= 1536) launch_dma<2, 3, 2, 2>(ARGS);   // 64 x 64 tiles, three workgroups per CU
             else if (dma == 43) launch_dma<2, 3, 2, 2>(ARGS);          // 64 x 64 tile, 3 workgroups per CU
             else if (dma == 12) launch_dma<2, 5, 1, 2>(ARGS);          // 32 x 64 tile
             else launch_dma<2, 5, 2, 1>(ARGS);
