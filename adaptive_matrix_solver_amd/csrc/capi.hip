@@ -417,7 +417,7 @@ static LuWs make_ws(maus_ctx* c, int n, int G) {
     return w;
 }
 
-// three sub-batch streams: 300 candidate-steps/s against 291 / 290 / 277 / 279 with 1 / 2 / 4 / 6 (driver-shaped run, round 2)
+// up to three sub-batch streams, each sub-batch at least MAUS_LU_MIN_SUB (32) matrices (see maus_shifted_lu_solve)
 static int lu_stream_count() { const char* e = getenv("MAUS_LU_STREAMS"); int v = e ? atoi(e) : 3; return std::max(1, std::min(8, v)); }
 
 static int ensure_lu_streams(maus_ctx* c, int n) {
@@ -541,10 +541,11 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             dU = c->Upert;
         }
         // Sub-batches on their own streams (at least 32 matrices each): the bandwidth- and latency-bound phases of one
-        // sub-batch (panel, triangular solves, H build) run beside the MFMA-bound trailing updates of the others.  The gain
-        // is bounded -- a streaming kernel beside the zgemm hides ~30 % of its time at best (tools/probe_corun.hip) --
+        // sub-batch (panel, triangular solves, H build) run beside the MFMA-bound trailing updates of the others.  The
+        // gain is bounded -- a streaming kernel beside the zgemm hides ~30 % of its time at best (tools/probe_corun.hip) --
         // and more sub-batches mean smaller, less efficient launches: 1 / 2 / 3 / 4 / 6 streams gave 291 / 290 / 300 /
-        // 277 / 279 candidate-steps/s on the driver-shaped run (n=4096, 176-331 solves per step).
+        // 277 / 279 candidate-steps/s on the driver-shaped run (n=4096, 176-331 solves per step), and with the DMA zgemm a
+        // minimum sub-batch of 32 / 48 / 64 / 128 matrices 338.9 / 337.8 / 338.0 / 333.1.
         static const int min_sub = [] { const char* e = getenv("MAUS_LU_MIN_SUB"); return e ? std::max(1, atoi(e)) : 32; }();
         const int S = std::max(1, std::min(nst, G / min_sub));
         if (S > 1) HIPCHK(c, hipEventRecord(c->ev_stage, c->st));

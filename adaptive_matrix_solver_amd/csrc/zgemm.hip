@@ -539,15 +539,17 @@ void maus_zgemm_launch_rows(hipStream_t st, int M, int N, int K, const c128* A, 
         // problem so that no MFMA runs on padding.
         if (N <= 16) { launch_lu_only<128, 16, 16, 4, 1>(ARGS); return; }
         if (M <= 16) { launch_lu_only<16, 128, 16, 1, 4, false, 3>(ARGS); return; }
-        // K >= 256 (the trailing updates proper, 92 % of the flops): the LDS-DMA staged 3M kernel.  Measured on MI355X
-        // (tools/gemm_k512_check.py, 3584 x 3616 x 512, 136 matrices, 8MNK-equivalent TFLOP/s): 83.6 against 79.2 for the
-        // register-staged kernel below -- without staging registers it fits 87 VGPRs and FIVE workgroups share a CU (six:
-        // 82.6; a ring of three buffers at four per CU: 78.1; 64 x 64 tiles at three / four per CU: 82.1 / 82.2 (spills);
-        // 32 x 64: 82.1).  Same summation order as the register-staged kernel, hence the same bits.  The K = 64 / 128
-        // levels of the recursion do not gain (too few K-steps per tile) and keep the kernel below.  MAUS_GEMM_DMA=0
-        // switches back.
+        // K >= 64: the LDS-DMA staged 3M kernel.  Measured on MI355X (tools/gemm_k512_check.py, 3584 x 3616 x 512, 136
+        // matrices, 8MNK-equivalent TFLOP/s): register-staged kernel below 79.2; DMA staging, 64 x 32 tiles, five workgroups
+        // per CU (87 VGPRs without the staging registers): 83.6 with the prefetch issued before the fragment reads, **86.8**
+        // with it issued behind them (see the kernel); 64 x 64 tiles at three workgroups per CU **88.7** on large updates
+        // (86.3 at 1024 x 1056: the 64 x 32 form is kept below 1536); six per CU 69 (spills), a ring of three buffers at
+        // four per CU 85.1, 32 x 64 tiles 86.9, the DMA from inline asm 84.1.  Same summation order as the register-staged
+        // kernel, hence the same bits.  The recursion levels K = 128 / 64 gain 8 % / 3 %, K <= 32 nothing.
+        // MAUS_GEMM_DMA=0 switches back.
         static const int dma = [] { const char* e = getenv("MAUS_GEMM_DMA"); return e ? atoi(e) : 1; }();
-        if (use3m && dma && M > 32 && (K % 8) == 0 && K >= 256) {
+        static const int dma_kmin = [] { const char* e = getenv("MAUS_GEMM_DMA_KMIN"); return e ? atoi(e) : 64; }();
+        if (use3m && dma && M > 32 && (K % 8) == 0 && K >= dma_kmin) {
             if (dma == 3) launch_dma<3, 4, 2, 1>(ARGS);
             else if (dma == 44) launch_dma<2, 4, 2, 2>(ARGS);
             else if (dma == 1 && M >= 1536 && N >= 1536) launch_dma<2, 3, 2, 2>(ARGS);   // 64 x 64 tiles, three workgroups per CU

@@ -344,7 +344,7 @@ def main():
             "per_step_summary": {"ms_per_candidate_step_median": round(float(np.median(ms_norm)), 4),
                                  "ms_per_candidate_step_max": round(float(np.max(ms_norm)), 4),
                                  "lu_workspace_allocations_total": ws_allocs},
-            "roofline": {"bound": "mfma", "kernel": "zgemm_kernel<64,32,16,3M>, K>=256 launches (LU trailing updates, v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "kernel": "zgemm3m_dma_kernel (LDS-DMA staged 3M zgemm, 64x64 / 64x32 tiles), K>=256 launches (LU trailing updates, v_mfma_f64_16x16x4_f64)",
                          # achieved / frac: real flops EXECUTED on the matrix pipe (3M: 6*M*N*K per complex GEMM) over the
                          # union of the launches' intervals; the algorithmic (8*M*N*K) rate is a side field
                          "achieved": alg * exec_ratio, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

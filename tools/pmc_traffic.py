@@ -76,7 +76,7 @@ for k, cs in acc.items():
 
 if "FETCH_SIZE" in big and "WRITE_SIZE" in big:
     f, w = big["FETCH_SIZE"], big["WRITE_SIZE"]
-    out = {"kernel": "zgemm_kernel<64,32,16,3M>, K>=256 launches of the LU trailing updates", "matrices": matrices,
+    out = {"kernel": "zgemm3m_dma_kernel (64x64 / 64x32 tiles, LDS-DMA staged 3M), K>=256 launches of the LU trailing updates", "matrices": matrices,
            "command": "MAUS_LU_STREAMS=1 MAUS_LU_TRACE=<file> rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace "
                       "-- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-isolated --no-small-batch --skip-diagnosis --kernel-events off",
            "launches": f[0], "fetch_bytes_per_launch": f[1] * 1024.0 * 2.0 / f[0], "write_bytes_per_launch": w[1] * 1024.0 / w[0],
