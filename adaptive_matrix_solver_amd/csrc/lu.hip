@@ -983,8 +983,8 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
 
 // U[j..j+TW, cols] = L11^-1 * H[perm[j..j+TW), cols]: the pivot rows are gathered through perm and their finished U
 // rows written to the logical-order array.
-template <int TW>
-__global__ void __launch_bounds__(256)
+template <int TW, int BS = 256>
+__global__ void __launch_bounds__(BS)
 trsm_ip_kernel(const c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long strideH, const int* __restrict__ perm_g,
                int npad, int j, int c_lo, int c_hi)
 {
@@ -1113,8 +1113,17 @@ static void lu_trsm(const LuWs& w, int j, int k, int c_lo, int c_hi) {
         prof(w, KC_TRSM, 0);
         dim3 grid((c_hi - c_lo + 255) / 256, w.G);
         if (lu_implicit()) {
-            if (k == 32 && NBP < 32) hipLaunchKernelGGL((trsm_ip_kernel<32>), grid, dim3(256), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
-            else hipLaunchKernelGGL((trsm_ip_kernel<NBP>), grid, dim3(256), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+            // small batches: one wave per workgroup, four times as many workgroups (a thread walks its 32 rows one after
+            // the other; with one 256-thread workgroup per CU or less nothing hides the latency of its loads)
+            const bool thin = (long)grid.x * w.G < 1024;
+            dim3 g64((c_hi - c_lo + 63) / 64, w.G);
+            if (k == 32 && NBP < 32) {
+                if (thin) hipLaunchKernelGGL((trsm_ip_kernel<32, 64>), g64, dim3(64), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+                else hipLaunchKernelGGL((trsm_ip_kernel<32>), grid, dim3(256), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+            } else {
+                if (thin) hipLaunchKernelGGL((trsm_ip_kernel<NBP, 64>), g64, dim3(64), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+                else hipLaunchKernelGGL((trsm_ip_kernel<NBP>), grid, dim3(256), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+            }
         }
         else if (k == 32 && NBP < 32) hipLaunchKernelGGL((trsm32_kernel<32>), grid, dim3(256), 0, w.st, w.H, w.ldh, w.strideH, j, c_lo, c_hi);
         else hipLaunchKernelGGL((trsm32_kernel<NBP>), grid, dim3(256), 0, w.st, w.H, w.ldh, w.strideH, j, c_lo, c_hi);

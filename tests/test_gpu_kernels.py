@@ -20,7 +20,10 @@ def crand(rng, *shape):
 
 
 @pytest.mark.parametrize("M,N,K", [(16, 16, 4), (64, 64, 16), (5, 7, 3), (100, 130, 77), (256, 64, 512),
-                                   (129, 65, 33), (300, 4096, 64), (1024, 1024, 256)])
+                                   (129, 65, 33), (300, 4096, 64), (1024, 1024, 256),
+                                   # the LDS-DMA staged 3M kernel: 64 x 64 tiles (M, N >= 1536) with ragged edges and a K that
+                                   # is a multiple of 8 only; 64 x 32 tiles with a ragged N
+                                   (1600, 1700, 72), (1990, 1540, 128), (200, 1111, 200)])
 @pytest.mark.parametrize("b_layout", [0, 1])
 def test_zgemm_matches_numpy(ctx, M, N, K, b_layout):
     rng = np.random.default_rng(M * 1000 + N + K)

@@ -43,5 +43,12 @@ for G in sizes:
         status = ctx.shifted_lu_solve(sl, lam[:G], psi[:G], 0, PERT_MT19937, desc)
     dt = (time.perf_counter() - t0) / reps
     assert (status == 0).all()
-    print(f"G={G:4d}: {dt * 1e3:8.1f} ms per call, {dt * 1e3 / G:6.3f} ms per solve, {G / dt:7.1f} solves/s", flush=True)
+    line = f"G={G:4d}: {dt * 1e3:8.1f} ms per call, {dt * 1e3 / G:6.3f} ms per solve, {G / dt:7.1f} solves/s"
+    if os.environ.get("LU_BATCH_KERNELS"):            # one more call with every launch bracketed by HIP events
+        ctx.profile_enable(1)
+        ctx.shifted_lu_solve(sl, lam[:G], psi[:G], 0, PERT_MT19937, desc)
+        pr = ctx.profile_read()
+        ctx.profile_enable(False)
+        line += " | " + " ".join(f"{k}={v['ms']:.1f}" for k, v in pr.items() if v["ms"] > 0.05)
+    print(line, flush=True)
 ctx.close()
