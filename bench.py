@@ -189,12 +189,10 @@ def main():
     for _ in range(args.warmup):
         it += 1
         solver.loop_body(it)
-    if args.kernel_events == "sampled" and "MAUS_PROF_STRIDE" not in os.environ:
-        # keep the number of bracketed launches per step roughly constant: small per-rank populations have short
-        # kernels, and an event pair costs a pipeline drain
-        per_rank = max(1, args.pop // world)
-        scale = max(1, round(256 / per_rank))
-        os.environ["MAUS_PROF_STRIDE"] = f"{scale},0"
+    if args.kernel_events == "sampled":
+        # every K>=256 zgemm launch is bracketed (a few dozen per loop body on any rank): the union of the bracketed
+        # intervals is only meaningful when none is skipped
+        os.environ["MAUS_PROF_STRIDE"] = "1,0"
     mode = {"sampled": 2, "all": 1, "off": 0}[args.kernel_events]
     # wall time inside maus_shifted_lu_solve per loop body (the rest of a loop body: Rayleigh / relax / residual phases,
     # the host's RNG-event replay and population bookkeeping, collectives)
