@@ -56,6 +56,21 @@ def test_eig1024_steps_against_oracle():
 
 
 # ---------------------------------------------------------------------------------------------
+# configs[3] (Hermitian shortcut) as whole loop bodies at a size where the oracle's eigh-per-candidate still finishes in
+# seconds; the 8192 x 8192 run through MAUS_Solver is tools/c4_run.py (profiles/r02_c4_hermitian_8192_end_to_end.txt)
+# ---------------------------------------------------------------------------------------------
+def test_herm384_steps_against_oracle():
+    import test_gpu_step_parity as sp
+    scenarios.TRAJECTORIES["herm384"] = dict(kind="eig", build=("hermitian", 384, 384), P=24, iters=3, seed=9, tol=1e-8)
+    try:
+        ref, anorm = sp.oracle_run("herm384", 3)
+        got = sp.product_run("herm384", 3)
+        sp.compare(ref, got, anorm, "herm384", tie_tol=1e-13)
+    finally:
+        scenarios.TRAJECTORIES.pop("herm384", None)
+
+
+# ---------------------------------------------------------------------------------------------
 # configs[4]: 2048 x 2048 SVD, cond ~ 1e8 -- the alternating power step (AMS:233-242) and the SVD residual
 # (AMS:299-301) of one GPU's share of the 512 candidates against batched NumPy.  (Whole SVD loop bodies are
 # compared with the oracle at 64 x 48 in test_gpu_step_parity.py; at 2048^2 the oracle's per-candidate matvecs
