@@ -575,7 +575,24 @@ init_perm_kernel(int* __restrict__ perm_g, int npad)
     if (i < npad) perm_g[(long)blockIdx.y * npad + i] = i;
 }
 
+#ifdef MAUS_PANEL_CLOCK
+__device__ unsigned long long g_panel_clk[8];
+#define PCLK(i) do { if (tid == 0) { unsigned long long t_ = wall_clock64(); atomicAdd(&g_panel_clk[i], t_ - tclk); tclk = t_; } } while (0)
+#define PCLK_SYNC(i) do { __syncthreads(); PCLK(i); } while (0)
+#else
+#define PCLK(i)
+#define PCLK_SYNC(i)
+#endif
 // Left-looking base panel with implicit pivoting; structure and pivot rule of lu_panel_ll_kernel.
+// Where its time goes (in-kernel clocks, -DMAUS_PANEL_CLOCK + tools/panel_clocks.py, profiles/r02_panel_phase_clocks.txt):
+// per panel ~45 us (32 solves) to ~100 us (181 solves) in the left-looking loads, ~38 us in the 16 column steps (2.4 us
+// each, instruction-bound: ~800 instructions per step and wave at 4 rows per thread), ~20 us store + barrier, ~9 us (b').
+// One workgroup per matrix draws 20-30 GB/s -- a CU's share of the chip's bandwidth -- whatever the access pattern.
+// Measured and rejected in round 2 (each bit-identical to this kernel, none faster at 32 or 181 solves per call):
+// a column-major scratch copy of the panel (coalesced sub-block loads, but the two transpositions cost what they save:
+// 51.5 vs 53.6 ms per 181-solve sweep, 34.2 vs 30.0 at 32); 1024 threads per workgroup (69 vs 54 ms); one barrier per
+// column with per-wave candidate rows published before it, DPP maximum and pivot rows kept in LDS (67 vs 54 ms: the
+// column step is bound by its instruction count, not by its barriers).
 template <int RPT, int PWL>
 __global__ void __launch_bounds__(PT)
 lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long strideH, int j0, int m,
@@ -599,11 +616,15 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_info = 0;
+#ifdef MAUS_PANEL_CLOCK
+    unsigned long long tclk = wall_clock64();
+#endif
     c128 R[RPT][PWL];
     int pr[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) { const int r = tid + k * PT; pr[k] = (r < m) ? perm[r] : 0; }
 
+    PCLK(0);
 #pragma unroll
     for (int sb = 0; sb < NBP / PWL; ++sb) {
         const int c0 = sb * PWL;
@@ -622,6 +643,7 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
             }
             __syncthreads();
         }
+        PCLK(1);
         // (c') load this thread's rows of the sub-block, bringing them up to date on the way (pivot rows are done)
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
@@ -649,6 +671,7 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
                 for (int c = 0; c < PWL; ++c) R[k][c] = nw[c];
             }
         }
+        PCLK_SYNC(2);
 #pragma unroll
         for (int c = 0; c < PWL; ++c) {
             const int a = c0 + c;            // pivot position (panel-local logical row == column index)
@@ -732,6 +755,7 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
             }
             lds_barrier();     // s_piv / s_val / s_pphys are rewritten by the next column
         }
+        PCLK(3);
         // store the factored sub-block (L below the pivots; the pivot rows' own entries are only read back by (b'))
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
@@ -743,6 +767,7 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
             }
         }
         __syncthreads();       // the next sub-block reads these columns from memory
+        PCLK(4);
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) { const int r = tid + k * PT; if (r < m) perm[r] = pr[k]; }
@@ -1194,13 +1219,21 @@ static void lu_recurse(const LuWs& w, int j0, int wd) {
     lu_laswp(w, j0 + h, j0 + wd, j0, j0 + h);
 }
 
-// Maximum rows the base panel can own (8 rows per thread x 512 threads)
+#ifdef MAUS_PANEL_CLOCK
+extern "C" int maus_debug_panel_clocks(unsigned long long* out, int reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_clk), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_panel_clk), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+// Maximum rows the base panel can own (512 threads x 16 rows per thread in the 2-column sub-block variant)
 int maus_lu_max_npad() { return PT * 16; }
 #if MAUS_NBP == 16
 size_t maus_lu_mw_sync_bytes() { return sizeof(MwSync); }
 #else
 size_t maus_lu_mw_sync_bytes() { return 64; }
-#endif     // 16 rows per thread in the 2-column panel variant
+#endif
 
 // Factor all G matrices in the workspace and carry the augmented column through (L y = P b).
 void maus_lu_factor(const LuWs& w, int nbo) {

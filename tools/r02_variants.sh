@@ -1,4 +1,4 @@
-python -m pytest tests -m gpu -q -x > gpurun_out/r02_gputests_full.log 2>&1
-grep -n "passed\|failed\|^FAILED\|^E  " gpurun_out/r02_gputests_full.log | cut -c1-250 | head
-python bench.py > gpurun_out/r02_bench_final.json 2> gpurun_out/r02_bench_final.err
-python tools/bench_summary.py gpurun_out/r02_bench_final.json | cut -c1-300
+set -e
+MAUS_LU_STREAMS=1 MAUS_PANEL_MW=0 timeout -k 10 200 python tools/panel_clocks.py 32 > gpurun_out/panel_clocks_fast.txt 2>&1
+MAUS_LU_STREAMS=1 MAUS_PANEL_MW=0 timeout -k 10 200 python tools/panel_clocks.py 181 >> gpurun_out/panel_clocks_fast.txt 2>&1
+cat gpurun_out/panel_clocks_fast.txt
