@@ -8,9 +8,11 @@ n, P = int(os.environ.get("N", 4096)), int(os.environ.get("P", 256))
 A = scenarios.ginibre(n, n)
 np.random.seed(1234); random.seed(1234); SolutionCandidate._candidate_id_counter = 0
 s = MAUS_Solver(A, ProblemType.EIGENVALUE, initial_num_candidates=P, quiet=True, record_history=False)
-s.loop_body(1)
+W = int(os.environ.get("WARM", 1))
+for it in range(1, W + 1):
+    s.loop_body(it)
 pr = cProfile.Profile(); pr.enable()
-s.loop_body(2); s.loop_body(3)
+s.loop_body(W + 1); s.loop_body(W + 2)
 pr.disable()
 out = io.StringIO(); pstats.Stats(pr, stream=out).sort_stats("cumulative").print_stats(28)
 print("\n".join(l[:150] for l in out.getvalue().splitlines()[:60]))
