@@ -49,5 +49,13 @@ int main() {
     run("bits 0..63", q);
     std::vector<uint32_t> m8(8, 0x000000ffu);
     run("low byte of every word", m8);
+    std::vector<uint32_t> w0(8, 0); w0[0] = 0xffffffffu;
+    run("bits 0..31", w0);
+    std::vector<uint32_t> e8(8, 0x01010101u);
+    run("every 8th bit (i%8==0)", e8);
+    std::vector<uint32_t> p32(8, 0); for (int i = 0; i < 256; ++i) if ((i / 8) % 8 == 0) p32[i / 32] |= 1u << (i % 32);
+    run("bits with (i/8)%8==0", p32);
+    std::vector<uint32_t> c32(8, 0); for (int i = 0; i < 256; ++i) if ((i / 8) % 8 != 0) c32[i / 32] |= 1u << (i % 32);
+    run("complement of that", c32);
     return 0;
 }

@@ -1,8 +1,7 @@
 set -e
-for ms in 32 16 8; do for st in 2 3 4; do
-echo "## MIN_SUB=$ms STREAMS=$st"
-MAUS_LU_MIN_SUB=$ms MAUS_LU_STREAMS=$st timeout -k 10 200 python tools/lu_batch_rates.py 32 64 2>&1 | grep "G="
-done; done > gpurun_out/small_streams.txt 2>&1
-cat gpurun_out/small_streams.txt
-WARM=8 timeout -k 10 300 python tools/host_profile.py > gpurun_out/host_profile_it9.txt 2>&1
-head -50 gpurun_out/host_profile_it9.txt | cut -c1-160
+MAUS_LU_PARTITION=4 timeout -k 10 300 python -m pytest tests/test_gpu_bench_path.py -m gpu -q -x -k "two_streams or status_codes" > gpurun_out/part_tests.log 2>&1 || { tail -30 gpurun_out/part_tests.log; exit 1; }
+tail -1 gpurun_out/part_tests.log
+for k in 4 3 2; do
+MAUS_LU_PARTITION=$k timeout -k 10 300 python bench.py --no-cpu-baseline --no-small-batch --no-isolated --steps 12 --warmup 5 > gpurun_out/part$k.json 2> gpurun_out/part$k.err
+python tools/bench_summary.py gpurun_out/part$k.json | cut -c1-120
+done
