@@ -576,7 +576,7 @@ init_perm_kernel(int* __restrict__ perm_g, int npad)
 }
 
 #ifdef MAUS_PANEL_CLOCK
-__device__ unsigned long long g_panel_clk[8];
+__device__ unsigned long long g_panel_clk[16];
 #define PCLK(i) do { if (tid == 0) { unsigned long long t_ = wall_clock64(); atomicAdd(&g_panel_clk[i], t_ - tclk); tclk = t_; } } while (0)
 #define PCLK_SYNC(i) do { __syncthreads(); PCLK(i); } while (0)
 #else
@@ -842,12 +842,16 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
             for (int c = 0; c < NBP; ++c) R[k][c] = row[c];
         }
     }
+#ifdef MAUS_PANEL_CLOCK
+    unsigned long long tclk = wall_clock64();
+#endif
     int my_info = 0;
     bool aborted = false;         // workgroup-uniform: a rendezvous timed out (here or in a sibling workgroup)
     __syncthreads();
 
     // one instantiation per column (R is indexed by the column, so `a` must be a compile-time constant; a 16-fold
     // `#pragma unroll` of this body exceeds the unroller's size limit); after an abort the remaining steps are skipped
+    PCLK(8);
     auto step = [&](auto AC) {
       constexpr int a = decltype(AC)::value;
       if (!aborted) {
@@ -892,6 +896,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
             }
         }
         __syncthreads();
+        PCLK(9);
         // ---- publish (wave 0: candidate, wave 1: row a), drain, arrive ----
         if (wave == 0) {
             if (lane < 2 * NBP) mw_store((unsigned long long*)&sy->row[par][w][lane], __double_as_longlong(((const double*)s_row)[lane]));
@@ -904,6 +909,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        PCLK(10);
         if (tid == 0) {
             __hip_atomic_fetch_add(&sy->cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long target = (unsigned long long)(a + 1) * W;
@@ -918,6 +924,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
             }
         }
         __syncthreads();
+        PCLK(11);
         aborted = (s_abort != 0);
       }
       if (!aborted) {
@@ -937,6 +944,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
             }
         }
         __syncthreads();
+        PCLK(12);
         double gv = -1.0; int gp = INT_MAX, gw = 0, gphys = 0;
         for (int q = 0; q < W; ++q) {
             const double v = __longlong_as_double((long long)s_meta[q][0]);
@@ -948,6 +956,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         if (tid < 2 * NBP) ((double*)s_row)[tid] = none ? ((const double*)s_arow)[tid] : s_all[gw][tid];
         if (tid == 0) s_phys[0] = none ? s_phys[1] : gphys;
         __syncthreads();
+        PCLK(13);
         // ---- the interchange: the owners of logical rows a and p exchange register rows and physical rows ----
         if (p != a) {
 #pragma unroll
@@ -983,6 +992,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
             }
         }
         __syncthreads();
+        PCLK(14);
       }
     };
     static_assert(NBP == 16, "lu_panel_mw_kernel: 16 column steps");
@@ -1002,6 +1012,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         }
     }
     if (tid == 0 && w == 0 && my_info != 0 && info_g[g] == 0) info_g[g] = my_info;
+    PCLK(15);
 }
 
 #endif  // MAUS_NBP == 16
@@ -1221,7 +1232,7 @@ static void lu_recurse(const LuWs& w, int j0, int wd) {
 
 #ifdef MAUS_PANEL_CLOCK
 extern "C" int maus_debug_panel_clocks(unsigned long long* out, int reset) {
-    unsigned long long z[8] = {0};
+    unsigned long long z[16] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_clk), sizeof(z)) != hipSuccess) return -1;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_panel_clk), z, sizeof(z)) != hipSuccess) return -1;
     return 0;

@@ -32,12 +32,15 @@ desc = (st, 4 * n * n, 0, np.arange(G, dtype=np.int32))
 sl = list(range(G))
 ctx.shifted_lu_solve(sl, lam, psi, 0, PERT_MT19937, desc)
 lib = _cabi.load_library()
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 16)()
 lib.maus_debug_panel_clocks(out, 1)
 ctx.shifted_lu_solve(sl, lam, psi, 0, PERT_MT19937, desc)
 lib.maus_debug_panel_clocks(out, 1)
-names = ["prologue (perm load)", "(b') pivot-row block + solve", "(c') load + left-looking update", "column loop", "store + barrier", "-", "-", "-"]
+names = ["prologue (perm load)", "(b') pivot-row block + solve", "(c') load + left-looking update", "column loop", "store + barrier", "-", "-", "-",
+         "mw: load panel slice", "mw: scan, reduce, stage candidate", "mw: publish + drain", "mw: arrive + wait", "mw: read candidates", "mw: pick winner",
+         "mw: interchange + update", "mw: store slice"]
 tot = sum(out)
+print('(mw rows: summed over the W workgroups of a matrix)')
 print(f"G={G}: per matrix and factorisation (256 panels), ms of thread 0's wall clock; total {tot * 1e-5 / G:.2f} ms")
 for nm, v in zip(names, out):
     if v:
