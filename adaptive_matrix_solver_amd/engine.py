@@ -462,6 +462,12 @@ class DeviceEngine:
             self._finish(todo, A, b, strat)
 
     # ---- Hermitian shortcut (AMS:155-221) ----------------------------------------------
+    def seed_eigh(self, A, evals, evecs):
+        """eigh(A) computed by the caller (the start-up diagnostics took the condition number from it): use it as the
+        once-per-matrix decomposition of the shortcut."""
+        self.ctx.set_eigvecs(evecs)
+        self._eig_cache = (A, evals)
+
     def _hermitian(self, cands, A):
         from .solver import SolutionCandidate
         S = SolutionCandidate.State

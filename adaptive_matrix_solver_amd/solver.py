@@ -451,6 +451,9 @@ class MAUS_Solver:
         self.engine = engine if engine is not None else DeviceEngine(device=device, pert_mode=pert_mode,
                                                                      gmres_compat=gmres_compat, comm=comm)
         self.engine.bind_matrix(self.M)
+        seed = self.__dict__.pop("_eigh_seed", None)
+        if seed is not None:
+            self.engine.seed_eigh(*seed)
         self._record_history = record_history
         # distinctness / redundancy tests (AMS:432-451, 509-520): with at least `gram_min` converged candidates the
         # pairwise np.vdot calls are replaced by one device Gram block and vectorised comparisons (same greedy order,
@@ -507,6 +510,22 @@ class MAUS_Solver:
                     if trusted:
                         cond_num_val = kappa
                 diag_info["condition_number_is_estimate"] = cond_num_val is not None
+                if (cond_num_val is None and diag_info["is_hermitian"] and self.problem_type == ProblemType.EIGENVALUE
+                        and getattr(self, "_cond_device", None) is not None and matrix.shape[0] > self._cond_exact_max):
+                    # the estimate fell into the guard band of a threshold.  A Hermitian eigenproblem decomposes the matrix
+                    # anyway (AMS:161, once per matrix here), and sigma_i = |lambda_i|: take the 2-norm condition number
+                    # from the eigenvalues and hand the decomposition to the engine instead of running an SVD on top
+                    # (44 s + 70 s at n = 8192, profiles/r02_c4_hermitian_8192_end_to_end.txt)
+                    import scipy.linalg as sla
+                    try:
+                        evals, evecs = sla.eigh(matrix)
+                        amax, amin = float(np.abs(evals).max()), float(np.abs(evals).min())
+                        with np.errstate(divide="ignore"):
+                            cond_num_val = np.float64(amax) / np.float64(amin)
+                        self._eigh_seed = (matrix, evals, evecs)
+                        diag_info["condition_number_from_eigh"] = True
+                    except np.linalg.LinAlgError:
+                        cond_num_val = None
                 if cond_num_val is None:
                     cond_num_val = np.linalg.cond(matrix)
                 if np.isinf(cond_num_val) or cond_num_val > 1e15:

@@ -49,3 +49,39 @@ def test_solver_decisions_unchanged(name):
     assert fast.strat_params == exact.strat_params
     if not expect_trusted:
         assert fast.cond_number == exact.cond_number        # the exact value was computed after all
+
+
+def test_hermitian_guard_band_takes_the_condition_number_from_eigh(monkeypatch):
+    """Hermitian eigenproblem whose estimate lands near the 1e6 threshold: the decomposition the shortcut needs anyway
+    (AMS:161) also yields the condition number (sigma_i = |lambda_i|), no SVD runs, and the first loop body reuses it."""
+    import scipy.linalg as sla
+    from adaptive_matrix_solver_amd.solver import MAUS_Solver, ProblemType, SolutionCandidate
+    n = 1100
+    rng = np.random.default_rng(17)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    d = np.logspace(0.0, -6.3, n) * np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    A = (Q * d) @ Q.conj().T
+    A = (A + A.conj().T) / 2
+    exact = np.linalg.cond(A)
+    assert 1e6 < exact < 30e6                                  # inside the 30x guard band of the 1e6 threshold
+    calls = {"eigh": 0, "cond": 0}
+    real_eigh, real_cond = sla.eigh, np.linalg.cond
+    monkeypatch.setattr(sla, "eigh", lambda *a, **k: (calls.__setitem__("eigh", calls["eigh"] + 1), real_eigh(*a, **k))[1])
+    monkeypatch.setattr(np.linalg, "cond", lambda *a, **k: (calls.__setitem__("cond", calls["cond"] + 1), real_cond(*a, **k))[1])
+    np.random.seed(5)
+    import random
+    random.seed(5)
+    SolutionCandidate._candidate_id_counter = 0
+    s = MAUS_Solver(A, ProblemType.EIGENVALUE, initial_num_candidates=12, quiet=True)
+    assert s.diag_info.get("condition_number_from_eigh") is True and not s.diag_info["condition_number_is_estimate"]
+    assert calls == {"eigh": 1, "cond": 0}
+    assert abs(s.cond_number - exact) <= 1e-8 * exact
+    assert s.problem_knowledge["numerical_stability_state"] == "Fragile"
+    s.loop_body(1)
+    assert calls["eigh"] == 1                                  # the shortcut used the seeded decomposition
+    # every initial candidate took the shortcut (AMS:176: CONVERGED; duplicates of an eigenpair may be retired by
+    # _manage_candidates afterwards), the spawned ones were never stepped
+    done = [c for c in s.candidates if c.id < 12]
+    assert done and all(c.state in (SolutionCandidate.State.CONVERGED, SolutionCandidate.State.RETIRED) for c in done)
+    lam = np.array([c.lambda_k for c in done])
+    assert np.abs(lam[:, None] - d[None, :]).min(axis=1).max() <= 1e-10

@@ -28,12 +28,6 @@ except Exception:
 t0 = time.perf_counter()
 A = scenarios.hermitian(n, 8192)
 print(f"matrix {n}x{n} Hermitian ((B+B^H)/2, B Ginibre/sqrt(n)) built in {time.perf_counter() - t0:.1f} s", flush=True)
-np.random.seed(1234); random.seed(1234); SolutionCandidate._candidate_id_counter = 0
-t0 = time.perf_counter()
-solver = MAUS_Solver(A, ProblemType.EIGENVALUE, initial_num_candidates=P, global_convergence_tol=1e-8, quiet=True, record_history=False)
-t_build = time.perf_counter() - t0
-print(f"solver construction: {t_build:.1f} s (Hermitian={solver.problem_knowledge['is_hermitian']}, cond={solver.cond_number:.3e}, "
-      f"estimate={solver.diag_info.get('condition_number_is_estimate')})", flush=True)
 import scipy.linalg as sla
 _eigh = sla.eigh
 t_eigh = [0.0]
@@ -47,6 +41,14 @@ def timed_eigh(*a, **k):
 
 
 sla.eigh = timed_eigh
+np.random.seed(1234); random.seed(1234); SolutionCandidate._candidate_id_counter = 0
+t0 = time.perf_counter()
+solver = MAUS_Solver(A, ProblemType.EIGENVALUE, initial_num_candidates=P, global_convergence_tol=1e-8, quiet=True, record_history=False)
+t_build = time.perf_counter() - t0
+print(f"solver construction: {t_build:.1f} s, of which host eigh {t_eigh[0]:.1f} s (Hermitian={solver.problem_knowledge['is_hermitian']}, "
+      f"cond={solver.cond_number:.3e}, estimate={solver.diag_info.get('condition_number_is_estimate')}, "
+      f"from eigh={solver.diag_info.get('condition_number_from_eigh', False)})", flush=True)
+eigh_at_build = t_eigh[0]
 rows = []
 for it in range(1, 4):
     t0 = time.perf_counter()
@@ -58,7 +60,7 @@ for it in range(1, 4):
           f"distinct converged {solver.num_distinct_converged_solutions}, population {len(solver.candidates)}", flush=True)
 first = rows[0]
 later = rows[1:]
-print(f"SUMMARY n={n} P={P}: host eigh (once per matrix) {t_eigh[0]:.1f} s; first loop body without it {first[2] - t_eigh[0]:.3f} s; "
+print(f"SUMMARY n={n} P={P}: host eigh (once per matrix) {t_eigh[0]:.1f} s; first loop body without it {first[2] - (first[3] - eigh_at_build):.3f} s; "
       f"later loop bodies {', '.join(f'{r[2] * 1e3:.1f} ms / {r[1]} steps' for r in later)}; "
       f"the reference would call eigh {first[1]} times in the first iteration alone ({first[1] * t_eigh[0] / 3600:.1f} h at this speed)")
 c = solver.candidates[0]
