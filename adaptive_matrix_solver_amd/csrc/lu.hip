@@ -12,12 +12,13 @@
 //     forward substitution L y = P b happens inside the factorisation and only U x = y remains.
 //   * right-looking outer blocks of NBO (512) columns; each block column is factored by a host-driven
 //     recursion (halving down to 16-wide panels) so that every flop outside the base panels is a
-//     call of the MFMA zgemm; row swaps are applied inside the block window by the recursion and,
-//     to the right of it, once per outer block (the L part to the left is never needed again
-//     because y is carried in the augmented column).
-//   * base panel (16 columns): one workgroup per matrix, rows owned by threads, 4- or 2-column
-//     sub-blocks kept in registers and brought up to date left-looking while they are loaded;
-//     pivot rule = LAPACK izamax (max |re|+|im|, first index wins).
+//     call of the MFMA zgemm.  The L part to the left of a block is never needed again because y is
+//     carried in the augmented column.
+//   * implicit row pivoting: rows never move, every kernel addresses them through perm[] (see below);
+//     finished U rows are collected in a second array in logical order.
+//   * base panel (16 columns): one workgroup per matrix (several for small batches), rows owned by
+//     threads, 4- or 2-column sub-blocks kept in registers and brought up to date left-looking while
+//     they are loaded; pivot rule = LAPACK izamax (max |re|+|im|, first index wins).
 #include "common.h"
 #include "luws.h"
 #include <cstdio>
@@ -124,444 +125,10 @@ load_h_kernel(const c128* __restrict__ Ain /*[G][n][n]*/, const c128* __restrict
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[g], 1);
 }
 
-// ---------------------------------------------------------------------------------------
-// Base panel, right-looking predecessor (MAUS_PANEL_LL=0; kept for A/B measurements): LU with partial
-// pivoting of the m x NBP block at (j0, j0), m = npad - j0.  One workgroup (512 threads) per matrix; thread t
-// owns rows t, t+512, ... (RPT of them).  Right-looking over 4-column sub-blocks held in registers.
-// ---------------------------------------------------------------------------------------
-template <int RPT>
-__global__ void __launch_bounds__(PT)
-lu_panel_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
-                int* __restrict__ ipiv_g, int npad, int* __restrict__ info_g, int dbg)
-{
-    c128* P = Hg + (long)blockIdx.x * strideH + (long)j0 * ld + j0;
-    int* ipiv = ipiv_g + (long)blockIdx.x * npad + j0;
-
-    __shared__ c128 s_piv[PW];
-    __shared__ c128 s_old[PW];
-    __shared__ double s_val[PT / 64];
-    __shared__ int s_idx[PT / 64];
-    __shared__ c128 s_L[PW][PW];
-    __shared__ c128 s_U[PW][NBP];
-    __shared__ int s_info;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_info = 0;
-    c128 R[RPT][PW];
-
-    for (int sb = 0; sb < NBP / PW; ++sb) {
-        const int c0 = sb * PW;
-        // (a) load this thread's rows of the sub-block
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int r = tid + k * PT;
-            if (r < m && !(dbg & 8)) {
-#pragma unroll
-                for (int c = 0; c < PW; ++c) R[k][c] = P[(long)r * ld + c0 + c];
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < PW; ++c) {
-            if (dbg & 1) break;
-            const int a = c0 + c;            // pivot position (panel-local row == column index)
-            // ---- pivot search: max |re|+|im| over rows >= a, first index wins ----
-            double best = -1.0; int bidx = INT_MAX;
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = tid + k * PT;
-                if (r < m && r >= a) {
-                    double v = cabs1(R[k][c]);
-                    if (v > best) { best = v; bidx = r; }
-                }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                double ov = __shfl_xor(best, o, 64);
-                int oi = __shfl_xor(bidx, o, 64);
-                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-            }
-            if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
-            __syncthreads();
-            best = s_val[0]; bidx = s_idx[0];
-#pragma unroll
-            for (int w = 1; w < PT / 64; ++w) {
-                double ov = s_val[w]; int oi = s_idx[w];
-                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-            }
-            const int p = (bidx == INT_MAX) ? a : bidx;   // all-NaN column: no swap (input flagged non-finite)
-            // ---- publish pivot row / displaced row of the register sub-block ----
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = tid + k * PT;
-                if (r == p) {
-#pragma unroll
-                    for (int cc = 0; cc < PW; ++cc) s_piv[cc] = R[k][cc];
-                }
-                if (r == a && p != a) {
-#pragma unroll
-                    for (int cc = 0; cc < PW; ++cc) s_old[cc] = R[k][cc];
-                }
-            }
-            // the other 28 panel columns are swapped in memory
-            if (p != a && tid < NBP && (tid < c0 || tid >= c0 + PW) && !(dbg & 32)) {
-                c128 x = P[(long)a * ld + tid], y = P[(long)p * ld + tid];
-                P[(long)a * ld + tid] = y; P[(long)p * ld + tid] = x;
-            }
-            if (tid == 0) ipiv[a] = j0 + p;
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = tid + k * PT;
-                if (p != a) {
-                    if (r == a) {
-#pragma unroll
-                        for (int cc = 0; cc < PW; ++cc) R[k][cc] = s_piv[cc];
-                    } else if (r == p) {
-#pragma unroll
-                        for (int cc = 0; cc < PW; ++cc) R[k][cc] = s_old[cc];
-                    }
-                }
-            }
-            const c128 pv = s_piv[c];
-            const bool zero_piv = (pv.x == 0.0 && pv.y == 0.0);
-            if (zero_piv && tid == 0 && s_info == 0) s_info = j0 + a + 1;   // LAPACK info (1-based)
-            const c128 rinv = zero_piv ? cmake(1.0, 0.0) : crecip(pv);
-            c128 prow[PW];
-#pragma unroll
-            for (int cc = 0; cc < PW; ++cc) prow[cc] = s_piv[cc];
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = tid + k * PT;
-                if (r < m && r > a) {
-                    c128 l = cmul(R[k][c], rinv);
-                    R[k][c] = l;
-#pragma unroll
-                    for (int cc = c + 1; cc < PW; ++cc) cfms(R[k][cc], l, prow[cc]);
-                }
-            }
-            __syncthreads();   // s_piv / s_val are rewritten by the next column
-        }
-        // (c) store the factored sub-block; rows c0..c0+3 also go to LDS (L11 of the sub-block)
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int r = tid + k * PT;
-            if (r < m && !(dbg & 16)) {
-#pragma unroll
-                for (int c = 0; c < PW; ++c) P[(long)r * ld + c0 + c] = R[k][c];
-                if (r >= c0 && r < c0 + PW) {
-#pragma unroll
-                    for (int c = 0; c < PW; ++c) s_L[r - c0][c] = R[k][c];
-                }
-            }
-        }
-        __syncthreads();
-        const int nt = NBP - c0 - PW;     // trailing panel columns
-        if (nt > 0) {
-            // (d) U12 = L11^-1 * A12 for the 4 pivot rows (unit lower), one lane per column
-            if (tid < nt && !(dbg & 4)) {
-                const int cc = c0 + PW + tid;
-                c128 u[PW];
-#pragma unroll
-                for (int i = 0; i < PW; ++i) u[i] = P[(long)(c0 + i) * ld + cc];
-#pragma unroll
-                for (int i = 1; i < PW; ++i)
-#pragma unroll
-                    for (int q = 0; q < i; ++q) cfms(u[i], s_L[i][q], u[q]);
-#pragma unroll
-                for (int i = 0; i < PW; ++i) { P[(long)(c0 + i) * ld + cc] = u[i]; s_U[i][tid] = u[i]; }
-            }
-            __syncthreads();
-            // (e) rank-4 update of the trailing panel columns for the rows below the sub-block, on the
-            //     matrix cores: C[16x16] -= L[16x4] * U12[4x16] is one K=4 step of v_mfma_f64_16x16x4
-            //     (x4 for the complex product).  Tiles are loaded/stored a[row=l&15][k=l>>4],
-            //     c[r] = C[row=(l>>4)+4r][col=l&15]: 256 contiguous bytes per row and instruction,
-            //     instead of the one-row-per-lane pattern of the register sub-block.
-            if (!(dbg & 2)) {
-                const int rmin = c0 + PW;
-                const int ntile = (m + 15) >> 4;
-                const int j0t = rmin >> 4;                       // first column tile that still has work (0 or 1)
-                constexpr int NCT = (NBP + 15) / 16;            // 16-column tiles across the panel
-                c128 bv[NCT];
-#pragma unroll
-                for (int j = 0; j < NCT; ++j) {
-                    const int cc = 16 * j + (lane & 15) - rmin;
-                    bv[j] = (cc >= 0 && cc < NBP - rmin) ? s_U[lane >> 4][cc] : cmake(0.0, 0.0);
-                }
-                // two row tiles per iteration and both column tiles: up to 18 independent 1-KB loads in
-                // flight per wave (this phase is bound by memory-level parallelism per CU)
-                for (int t = (rmin >> 4) + 2 * wave; t < ntile; t += 2 * (PT / 64)) {
-                    c128 av[2], cv[2][NCT][4];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int arow = min(16 * (t + u) + (lane & 15), m - 1);
-                        av[u] = P[(long)arow * ld + c0 + (lane >> 4)];
-#pragma unroll
-                        for (int j = 0; j < NCT; ++j)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = min(16 * (t + u) + (lane >> 4) + 4 * r, m - 1);
-                                const int col = min(16 * j + (lane & 15), NBP - 1);
-                                cv[u][j][r] = (j >= j0t) ? P[(long)row * ld + col] : cmake(0.0, 0.0);
-                            }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int j = 0; j < NCT; ++j) {
-                            if (j < j0t) continue;
-                            d4 cre, cim;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { cre[r] = cv[u][j][r].x; cim[r] = cv[u][j][r].y; }
-                            cre = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].x, bv[j].x, cre, 0, 0, 1);   // -= Lre*Ure
-                            cim = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].x, bv[j].y, cim, 0, 0, 1);   // -= Lre*Uim
-                            cre = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].y, bv[j].y, cre, 0, 0, 0);   // += Lim*Uim
-                            cim = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].y, bv[j].x, cim, 0, 0, 1);   // -= Lim*Ure
-                            const int col = 16 * j + (lane & 15);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = 16 * (t + u) + (lane >> 4) + 4 * r;
-                                if (row < m && row >= rmin && col >= rmin && col < NBP) P[(long)row * ld + col] = cmake(cre[r], cim[r]);
-                            }
-                        }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (tid == 0 && s_info != 0 && info_g[blockIdx.x] == 0) info_g[blockIdx.x] = s_info;
-}
-
-// ---------------------------------------------------------------------------------------
-// Left-looking form of the panel kernel (default).  Same pivot rule and data ownership, but a 4-column
-// sub-block applies the updates of the EARLIER sub-blocks to its own columns while loading them
-//     R[r][c] = A[r][c0+c] - sum_{j<c0} L[r][j] * U[j][c0+c]
-// instead of every sub-block pushing a rank-4 update through memory into the columns to its right.
-// Per 16-wide panel that is 40 column reads + 16 column writes instead of 56 + 36, every row is read as one
-// contiguous piece of 64..256 bytes, and the MFMA rank-4 phase with its extra barriers is gone.
-//   (b') U[0:c0][c0:c0+4] = L00^-1 A[0:c0][c0:c0+4]   (unit-lower L00 of the finished sub-blocks, <= 12x12,
-//        forward substitution by one lane per column out of LDS)
-//   (c') row update above, U broadcast from LDS, L read from the row's own finished columns
-//   (d') the pivot steps on the register sub-block, exactly as in lu_panel_kernel
-// PWL = sub-block width: 4 columns with up to 8 rows per thread (m <= 4096), 2 columns with 16 rows per thread
-// (m <= 8192) -- the same 128 VGPRs of sub-block either way.
-// ---------------------------------------------------------------------------------------
-template <int RPT, int PWL>
-__global__ void __launch_bounds__(PT)
-lu_panel_ll_kernel(c128* __restrict__ Hg, long ld, long strideH, int j0, int m,
-                   int* __restrict__ ipiv_g, int npad, int* __restrict__ info_g)
-{
-    c128* P = Hg + (long)blockIdx.x * strideH + (long)j0 * ld + j0;
-    int* ipiv = ipiv_g + (long)blockIdx.x * npad + j0;
-
-    constexpr int LW = NBP - PWL;                 // widest finished part (12 columns)
-    __shared__ c128 s_piv[PWL];
-    __shared__ c128 s_old[PWL];
-    __shared__ double s_val[PT / 64];
-    __shared__ int s_idx[PT / 64];
-    __shared__ c128 s_L00[LW][LW];
-    __shared__ c128 s_U[LW][PWL];
-    __shared__ int s_info;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_info = 0;
-    c128 R[RPT][PWL];
-
-#pragma unroll
-    for (int sb = 0; sb < NBP / PWL; ++sb) {
-        const int c0 = sb * PWL;
-        if (sb > 0) {
-            // (b') U block of this sub-block's columns above the diagonal block
-            for (int e = tid; e < c0 * c0; e += PT) { const int j = e / c0, i = e - j * c0; s_L00[j][i] = P[(long)j * ld + i]; }
-            for (int e = tid; e < c0 * PWL; e += PT) { const int j = e / PWL, c = e - j * PWL; s_U[j][c] = P[(long)j * ld + c0 + c]; }
-            __syncthreads();
-            if (tid < PWL) {
-                for (int j = 1; j < c0; ++j) {
-                    c128 u = s_U[j][tid];
-                    for (int i = 0; i < j; ++i) cfms(u, s_L00[j][i], s_U[i][tid]);
-                    s_U[j][tid] = u;
-                }
-                for (int j = 0; j < c0; ++j) P[(long)j * ld + c0 + tid] = s_U[j][tid];
-            }
-            __syncthreads();
-        }
-        // (c') load this thread's rows of the sub-block, bringing them up to date on the way
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int r = tid + k * PT;
-            if (r < m) {
-                const c128* row = P + (long)r * ld;
-                c128 nw[PWL];
-#pragma unroll
-                for (int c = 0; c < PWL; ++c) nw[c] = row[c0 + c];
-                if (sb > 0 && r >= c0) {
-                    // one finished sub-block (4 columns = 64 bytes of the row) at a time: 16 VGPRs of L in flight
-#pragma unroll
-                    for (int pb = 0; pb < LW / PWL; ++pb) {
-                        if (pb < sb) {
-                            c128 l[PWL];
-#pragma unroll
-                            for (int j = 0; j < PWL; ++j) l[j] = row[pb * PWL + j];
-#pragma unroll
-                            for (int j = 0; j < PWL; ++j)
-#pragma unroll
-                                for (int c = 0; c < PWL; ++c) cfms(nw[c], l[j], s_U[pb * PWL + j][c]);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < PWL; ++c) R[k][c] = nw[c];
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < PWL; ++c) {
-            const int a = c0 + c;            // pivot position (panel-local row == column index)
-            // ---- pivot search: max |re|+|im| over rows >= a, first index wins ----
-            double best = -1.0; int bidx = INT_MAX;
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = tid + k * PT;
-                if (r < m && r >= a) {
-                    double v = cabs1(R[k][c]);
-                    if (v > best) { best = v; bidx = r; }
-                }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                double ov = __shfl_xor(best, o, 64);
-                int oi = __shfl_xor(bidx, o, 64);
-                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-            }
-            if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
-            lds_barrier();
-            best = s_val[0]; bidx = s_idx[0];
-#pragma unroll
-            for (int w = 1; w < PT / 64; ++w) {
-                double ov = s_val[w]; int oi = s_idx[w];
-                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-            }
-            const int p = (bidx == INT_MAX) ? a : bidx;   // all-NaN column: no swap (input flagged non-finite)
-            // ---- publish pivot row / displaced row of the register sub-block ----
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = tid + k * PT;
-                if (r == p) {
-#pragma unroll
-                    for (int cc = 0; cc < PWL; ++cc) s_piv[cc] = R[k][cc];
-                }
-                if (r == a && p != a) {
-#pragma unroll
-                    for (int cc = 0; cc < PWL; ++cc) s_old[cc] = R[k][cc];
-                }
-            }
-            // the other 12 panel columns are swapped in memory: finished L columns to the left, raw (not yet
-            // updated) columns to the right -- their pending updates use the swapped L rows, so this commutes
-            if (p != a && tid < NBP && (tid < c0 || tid >= c0 + PWL)) {
-                c128 x = P[(long)a * ld + tid], y = P[(long)p * ld + tid];
-                P[(long)a * ld + tid] = y; P[(long)p * ld + tid] = x;
-            }
-            if (tid == 0) ipiv[a] = j0 + p;
-            lds_barrier();         // only s_piv / s_old cross threads here; the swapped columns are re-read by their own thread
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = tid + k * PT;
-                if (p != a) {
-                    if (r == a) {
-#pragma unroll
-                        for (int cc = 0; cc < PWL; ++cc) R[k][cc] = s_piv[cc];
-                    } else if (r == p) {
-#pragma unroll
-                        for (int cc = 0; cc < PWL; ++cc) R[k][cc] = s_old[cc];
-                    }
-                }
-            }
-            const c128 pv = s_piv[c];
-            const bool zero_piv = (pv.x == 0.0 && pv.y == 0.0);
-            if (zero_piv && tid == 0 && s_info == 0) s_info = j0 + a + 1;   // LAPACK info (1-based)
-            const c128 rinv = zero_piv ? cmake(1.0, 0.0) : crecip(pv);
-            c128 prow[PWL];
-#pragma unroll
-            for (int cc = 0; cc < PWL; ++cc) prow[cc] = s_piv[cc];
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = tid + k * PT;
-                if (r < m && r > a) {
-                    c128 l = cmul(R[k][c], rinv);
-                    R[k][c] = l;
-#pragma unroll
-                    for (int cc = c + 1; cc < PWL; ++cc) cfms(R[k][cc], l, prow[cc]);
-                }
-            }
-            lds_barrier();     // s_piv / s_val are rewritten by the next column
-        }
-        // store the factored sub-block
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int r = tid + k * PT;
-            if (r < m) {
-#pragma unroll
-                for (int c = 0; c < PWL; ++c) P[(long)r * ld + c0 + c] = R[k][c];
-            }
-        }
-        __syncthreads();       // the next sub-block reads these columns (and the rows it swapped) from memory
-    }
-    if (tid == 0 && s_info != 0 && info_g[blockIdx.x] == 0) info_g[blockIdx.x] = s_info;
-}
-
-// ---------------------------------------------------------------------------------------
-// Row interchanges ipiv[k1..k2) applied to columns [c_lo, c_hi); one thread per column.
-// (Measured and rejected: applying the net permutation of the block instead of the swap sequence, and issuing the
-// loads of 8 pairwise-independent swaps before their stores -- 56 and 70 ms per sweep against 49 for this loop.)
-// ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-laswp_kernel(c128* __restrict__ Hg, long ld, long strideH, const int* __restrict__ ipiv_g, int npad,
-             int k1, int k2, int c_lo, int c_hi)
-{
-    const int col = c_lo + blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= c_hi) return;
-    c128* H = Hg + (long)blockIdx.y * strideH + col;
-    const int* ipiv = ipiv_g + (long)blockIdx.y * npad;
-    for (int k = k1; k < k2; ++k) {
-        const int p = ipiv[k];
-        if (p != k) {
-            c128 x = H[(long)k * ld], y = H[(long)p * ld];
-            H[(long)k * ld] = y; H[(long)p * ld] = x;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// B <- L11^-1 B with L11 the TW x TW unit-lower block at (j, j), B = rows j..j+TW, cols [c_lo,c_hi); TW = 16 or 32.
-// One thread per column, L11 broadcast from LDS.
-// ---------------------------------------------------------------------------------------
-template <int TW>
-__global__ void __launch_bounds__(256)
-trsm32_kernel(c128* __restrict__ Hg, long ld, long strideH, int j, int c_lo, int c_hi)
-{
-    __shared__ c128 sL[TW][TW + 1];
-    c128* H = Hg + (long)blockIdx.y * strideH;
-    for (int e = threadIdx.x; e < TW * TW; e += blockDim.x) {
-        int r = e / TW, c = e % TW;
-        sL[r][c] = H[(long)(j + r) * ld + j + c];
-    }
-    __syncthreads();
-    const int col = c_lo + blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= c_hi) return;
-    c128 x[TW];
-#pragma unroll
-    for (int i = 0; i < TW; ++i) x[i] = H[(long)(j + i) * ld + col];
-#pragma unroll
-    for (int i = 1; i < TW; ++i)
-#pragma unroll
-        for (int q = 0; q < i; ++q) cfms(x[i], sL[i][q], x[q]);
-#pragma unroll
-    for (int i = 1; i < TW; ++i) H[(long)(j + i) * ld + col] = x[i];
-}
-
-
 // =======================================================================================
-// Implicit pivoting (default).  Rows never move: perm[i] is the physical row of H holding logical row i, a row
+// Implicit pivoting.  Rows never move: perm[i] is the physical row of H holding logical row i, a row
 // interchange is a swap of two perm entries, and every kernel addresses rows through perm (the zgemm gathers its A / C
-// rows through the same list).  That removes the laswp sweeps altogether -- 600 MB of HBM traffic per matrix and
+// rows through the same list).  That removes round 1's row-swap sweeps altogether -- 600 MB of HBM traffic per matrix and
 // factorisation at n = 4096 (each outer block's 512 interchanges applied to everything to its right, plus the
 // interchanges inside the block column at every recursion level), 5 % of the step -- and the in-panel swaps of the
 // other 12 panel columns.  The pivot choice is unchanged: the search runs over LOGICAL row indices, first index wins,
@@ -583,7 +150,20 @@ __device__ unsigned long long g_panel_clk[16];
 #define PCLK(i)
 #define PCLK_SYNC(i)
 #endif
-// Left-looking base panel with implicit pivoting; structure and pivot rule of lu_panel_ll_kernel.
+// Base panel: LU with partial pivoting of the m x NBP block at (j0, j0), m = npad - j0.  One workgroup (512 threads) per
+// matrix; thread t owns the logical rows t, t+512, ... (RPT of them) and keeps one PWL-column sub-block of them in
+// registers.  Left-looking over the sub-blocks: a sub-block applies the updates of the EARLIER sub-blocks to its own columns
+// while loading them,
+//     R[r][c] = A[r][c0+c] - sum_{j<c0} L[r][j] * U[j][c0+c]
+// instead of every sub-block pushing a rank-PWL update through memory into the columns to its right: per 16-wide panel 40
+// column reads + 16 column writes instead of 56 + 36, every row read as one contiguous piece of 64..256 bytes.
+//   (b') U[0:c0][c0:c0+PWL] = L00^-1 A[pivot rows][c0:c0+PWL]   (unit-lower L00 of the finished sub-blocks, <= 12x12,
+//        forward substitution by one lane per column out of LDS)
+//   (c') the row update above, U broadcast from LDS, L read from the row's own finished columns
+//   (d') the pivot steps on the register sub-block: max |re|+|im| over the logical rows >= the diagonal, first index wins
+//        (LAPACK izamax); the two owner threads exchange register rows and the physical rows they stand for
+// PWL = 4 columns with up to 8 rows per thread (m <= 4096), 2 columns with 16 rows per thread (m <= 8192) -- the same 128
+// VGPRs of sub-block either way.
 // Where its time goes (in-kernel clocks, -DMAUS_PANEL_CLOCK + tools/panel_clocks.py, profiles/r02_panel_phase_clocks.txt):
 // per panel ~45 us (32 solves) to ~100 us (181 solves) in the left-looking loads, ~38 us in the 16 column steps (2.4 us
 // each, instruction-bound: ~800 instructions per step and wave at 4 rows per thread), ~20 us store + barrier, ~9 us (b').
@@ -1109,8 +689,6 @@ backsolve_kernel(const c128* __restrict__ Hg, long ld, long strideH, int n, int 
 
 static inline void prof(const LuWs& w, int klass, int phase, double flops = 0, double bytes = 0) { if (w.tick) w.tick(w.ud, klass, phase, flops, bytes); }
 
-static bool lu_implicit() { static const int v = [] { const char* e = getenv("MAUS_LU_IMPLICIT"); return e ? atoi(e) : 1; }(); return v != 0; }
-
 static void lu_gemm(const LuWs& w, int r0, int r1, int c0, int c1, int k0, int k1) {
     // H[r0:r1, c0:c1] -= H[r0:r1, k0:k1] * H[k0:k1, c0:c1]   (implicit pivoting: rows r0:r1 through perm, the
     // k0:k1 rows of the right factor are finished U rows and come from the logical-order array)
@@ -1122,23 +700,10 @@ static void lu_gemm(const LuWs& w, int r0, int r1, int c0, int c1, int k0, int k
     static FILE* trace = [] { const char* e = getenv("MAUS_LU_TRACE"); return e ? fopen(e, "a") : (FILE*)nullptr; }();
     if (trace) { fprintf(trace, "%d %d %d %d\n", M, N, K, w.G); fflush(trace); }
     prof(w, kc, 0);
-    if (lu_implicit())
-        maus_zgemm_launch_rows(w.st, M, N, K, w.H + k0, w.ldh, w.strideH,
-                               w.U + (long)k0 * w.ldh + c0, w.ldh, w.strideH,
-                               w.H + c0, w.ldh, w.strideH, -1.0, 1, w.G, 0, false, false, w.perm + r0, w.perm + r0, w.npad);
-    else
-    maus_zgemm_launch(w.st, M, N, K, w.H + (long)r0 * w.ldh + k0, w.ldh, w.strideH,
-                      w.H + (long)k0 * w.ldh + c0, w.ldh, w.strideH,
-                      w.H + (long)r0 * w.ldh + c0, w.ldh, w.strideH, -1.0, 1, w.G, 0, false, false);
+    maus_zgemm_launch_rows(w.st, M, N, K, w.H + k0, w.ldh, w.strideH,
+                           w.U + (long)k0 * w.ldh + c0, w.ldh, w.strideH,
+                           w.H + c0, w.ldh, w.strideH, -1.0, 1, w.G, 0, false, false, w.perm + r0, w.perm + r0, w.npad);
     prof(w, kc, 1, 8.0 * M * N * K * w.G, 16.0 * ((double)M * K + (double)K * N + 2.0 * M * N) * w.G);
-}
-
-static void lu_laswp(const LuWs& w, int k1, int k2, int c_lo, int c_hi) {
-    if (c_hi <= c_lo || k2 <= k1 || lu_implicit()) return;
-    prof(w, KC_LASWP, 0);
-    dim3 grid((c_hi - c_lo + 255) / 256, w.G);
-    hipLaunchKernelGGL(laswp_kernel, grid, dim3(256), 0, w.st, w.H, w.ldh, w.strideH, w.ipiv, w.npad, k1, k2, c_lo, c_hi);
-    prof(w, KC_LASWP, 1, 0, 64.0 * (k2 - k1) * (c_hi - c_lo) * w.G);
 }
 
 static void lu_trsm(const LuWs& w, int j, int k, int c_lo, int c_hi) {
@@ -1148,21 +713,17 @@ static void lu_trsm(const LuWs& w, int j, int k, int c_lo, int c_hi) {
     if (k <= NBP || (tw32 && k == 32)) {
         prof(w, KC_TRSM, 0);
         dim3 grid((c_hi - c_lo + 255) / 256, w.G);
-        if (lu_implicit()) {
-            // small batches: one wave per workgroup, four times as many workgroups (a thread walks its 32 rows one after
-            // the other; with one 256-thread workgroup per CU or less nothing hides the latency of its loads)
-            const bool thin = (long)grid.x * w.G < 1024;
-            dim3 g64((c_hi - c_lo + 63) / 64, w.G);
-            if (k == 32 && NBP < 32) {
-                if (thin) hipLaunchKernelGGL((trsm_ip_kernel<32, 64>), g64, dim3(64), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
-                else hipLaunchKernelGGL((trsm_ip_kernel<32>), grid, dim3(256), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
-            } else {
-                if (thin) hipLaunchKernelGGL((trsm_ip_kernel<NBP, 64>), g64, dim3(64), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
-                else hipLaunchKernelGGL((trsm_ip_kernel<NBP>), grid, dim3(256), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
-            }
+        // small batches: one wave per workgroup, four times as many workgroups (a thread walks its 32 rows one after
+        // the other; with one 256-thread workgroup per CU or less nothing hides the latency of its loads)
+        const bool thin = (long)grid.x * w.G < 1024;
+        dim3 g64((c_hi - c_lo + 63) / 64, w.G);
+        if (k == 32 && NBP < 32) {
+            if (thin) hipLaunchKernelGGL((trsm_ip_kernel<32, 64>), g64, dim3(64), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+            else hipLaunchKernelGGL((trsm_ip_kernel<32>), grid, dim3(256), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+        } else {
+            if (thin) hipLaunchKernelGGL((trsm_ip_kernel<NBP, 64>), g64, dim3(64), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+            else hipLaunchKernelGGL((trsm_ip_kernel<NBP>), grid, dim3(256), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
         }
-        else if (k == 32 && NBP < 32) hipLaunchKernelGGL((trsm32_kernel<32>), grid, dim3(256), 0, w.st, w.H, w.ldh, w.strideH, j, c_lo, c_hi);
-        else hipLaunchKernelGGL((trsm32_kernel<NBP>), grid, dim3(256), 0, w.st, w.H, w.ldh, w.strideH, j, c_lo, c_hi);
         prof(w, KC_TRSM, 1, 4.0 * k * k * (c_hi - c_lo) * w.G, 32.0 * k * (c_hi - c_lo) * w.G);
         return;
     }
@@ -1177,17 +738,13 @@ static void lu_panel(const LuWs& w, int j0) {
     prof(w, KC_PANEL, 0);
     dim3 grid(w.G), block(PT);
     int rpt = (m + PT - 1) / PT;
-    static const int dbg = [] { const char* e = getenv("MAUS_PANEL_DBG"); return e ? atoi(e) : 0; }();   // timing experiments only
-    static const int ll = [] { const char* e = getenv("MAUS_PANEL_LL"); return e ? atoi(e) : 1; }();
-#define PANEL(R) hipLaunchKernelGGL((lu_panel_kernel<R>), grid, block, 0, w.st, w.H, w.ldh, w.strideH, j0, m, w.ipiv, w.npad, w.info, dbg)
-#define PANEL_LL(R, W) hipLaunchKernelGGL((lu_panel_ll_kernel<R, W>), grid, block, 0, w.st, w.H, w.ldh, w.strideH, j0, m, w.ipiv, w.npad, w.info)
 #define PANEL_IP(R, W) hipLaunchKernelGGL((lu_panel_ip_kernel<R, W>), grid, block, 0, w.st, w.H, w.U, w.ldh, w.strideH, j0, m, w.ipiv, w.perm, w.npad, w.info)
     // Small batches: several workgroups per matrix (lu_panel_mw_kernel).  Only when the caller guarantees that this is the
     // only LU in flight on the device (w.mw_sync set) and all G*W workgroups fit on the chip at once -- the workgroups of a
     // matrix wait for each other.
 #if MAUS_NBP == 16
     static const int mw_on = [] { const char* e = getenv("MAUS_PANEL_MW"); return e ? atoi(e) : 1; }();
-    if (lu_implicit() && mw_on && w.mw_sync && m >= 1024) {
+    if (mw_on && w.mw_sync && m >= 1024) {
         static const int ncu = [] { int v = 0; int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
         auto p2floor = [](int x) { int p = 1; while (2 * p <= x) p *= 2; return p; };
         auto p2ceil = [](int x) { int p = 1; while (p < x) p *= 2; return p; };
@@ -1204,17 +761,8 @@ static void lu_panel(const LuWs& w, int j0) {
         }
     }
 #endif
-    if (lu_implicit()) {
-        if (rpt <= 1) PANEL_IP(1, 4); else if (rpt <= 2) PANEL_IP(2, 4); else if (rpt <= 4) PANEL_IP(4, 4);
-        else if (rpt <= 8) PANEL_IP(8, 4); else PANEL_IP(16, 2);
-    }
-    else if (ll || rpt > 8) {
-        if (rpt <= 1) PANEL_LL(1, 4); else if (rpt <= 2) PANEL_LL(2, 4); else if (rpt <= 4) PANEL_LL(4, 4);
-        else if (rpt <= 8) PANEL_LL(8, 4); else PANEL_LL(16, 2);
-    }
-    else { if (rpt <= 1) PANEL(1); else if (rpt <= 2) PANEL(2); else if (rpt <= 4) PANEL(4); else PANEL(8); }
-#undef PANEL
-#undef PANEL_LL
+    if (rpt <= 1) PANEL_IP(1, 4); else if (rpt <= 2) PANEL_IP(2, 4); else if (rpt <= 4) PANEL_IP(4, 4);
+    else if (rpt <= 8) PANEL_IP(8, 4); else PANEL_IP(16, 2);
 #undef PANEL_IP
     prof(w, KC_PANEL, 1, 8.0 * m * NBP * NBP / 2 * w.G, 16.0 * m * NBP * 8 * w.G);
 }
@@ -1223,11 +771,9 @@ static void lu_recurse(const LuWs& w, int j0, int wd) {
     if (wd <= NBP) { lu_panel(w, j0); return; }
     int h = (wd / (2 * NBP)) * NBP;
     lu_recurse(w, j0, h);
-    lu_laswp(w, j0, j0 + h, j0 + h, j0 + wd);
     lu_trsm(w, j0, h, j0 + h, j0 + wd);
     lu_gemm(w, j0 + h, w.npad, j0 + h, j0 + wd, j0, j0 + h);
     lu_recurse(w, j0 + h, wd - h);
-    lu_laswp(w, j0 + h, j0 + wd, j0, j0 + h);
 }
 
 #ifdef MAUS_PANEL_CLOCK
@@ -1249,11 +795,10 @@ size_t maus_lu_mw_sync_bytes() { return 64; }
 // Factor all G matrices in the workspace and carry the augmented column through (L y = P b).
 void maus_lu_factor(const LuWs& w, int nbo) {
     const int ncols = (int)w.ldh;                 // npad + 32
-    if (lu_implicit()) hipLaunchKernelGGL(init_perm_kernel, dim3((w.npad + 255) / 256, w.G), dim3(256), 0, w.st, w.perm, w.npad);
+    hipLaunchKernelGGL(init_perm_kernel, dim3((w.npad + 255) / 256, w.G), dim3(256), 0, w.st, w.perm, w.npad);
     for (int J = 0; J < w.npad; J += nbo) {
         int wd = (w.npad - J < nbo) ? (w.npad - J) : nbo;
         lu_recurse(w, J, wd);
-        lu_laswp(w, J, J + wd, J + wd, ncols);
         lu_trsm(w, J, wd, J + wd, ncols);
         lu_gemm(w, J + wd, w.npad, J + wd, ncols, J, J + wd);
     }
@@ -1267,7 +812,7 @@ void maus_lu_backsolve(const LuWs& w, c128* Wpop, long ldw, const int* d_slots, 
         (void)hipFuncSetAttribute((const void*)backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(backsolve_kernel, dim3(w.G), dim3(1024), shm, w.st, lu_implicit() ? w.U : w.H, w.ldh, w.strideH, w.n, w.npad,
+    hipLaunchKernelGGL(backsolve_kernel, dim3(w.G), dim3(1024), shm, w.st, w.U, w.ldh, w.strideH, w.n, w.npad,
                        Wpop, ldw, d_slots, xout_dense, w.flags);
     prof(w, KC_BACKSOLVE, 1, 4.0 * w.npad * w.npad * w.G, 8.0 * w.npad * w.npad * w.G);
 }

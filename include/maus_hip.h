@@ -207,7 +207,7 @@ int maus_lu_solve_host(maus_ctx* ctx, int count, int n, const double* a_c128, co
 int maus_timer_start(maus_ctx* ctx);
 int maus_timer_stop(maus_ctx* ctx, float* ms_out);
 /* Per-kernel-class accounting (event pairs around each launch of the class while enabled).
- * classes: 0 zgemm (LU trailing update with K>=256 / A@X), 1 lu_panel, 2 trsm, 3 laswp, 4 build_H, 5 backsolve,
+ * classes: 0 zgemm (LU trailing update with K>=256 / A@X), 1 lu_panel, 2 trsm, 3 (unused since round 2: row-swap sweeps), 4 build_H, 5 backsolve,
  * 6 vector ops, 7..10 zgemm inside the LU recursion with K = 128 / 64 / 32 / 16 */
 /* on = 1: event pairs around every launch of every class; on = 2: around the K>=256 zgemm launches only (class 0;
  * long kernels, so cheap enough for a timed region -- full bracketing costs 3-5 % of throughput; MAUS_PROF_STRIDE
