@@ -23,6 +23,14 @@ def test_library_exports_every_declared_symbol():
     assert lib.maus_abi_version() == 1
 
 
+def test_shipped_library_is_not_a_debug_build():
+    """`make EXTRA=-DMAUS_PANEL_CLOCK` adds in-kernel clocks and one extra export (tools/panel_clocks.py); the library in
+    the tree -- the one that travels to the GPU box -- must be the plain build."""
+    from adaptive_matrix_solver_amd import _cabi
+    lib = ctypes.CDLL(_cabi.LIB_PATH)
+    assert not hasattr(lib, "maus_debug_panel_clocks"), "libmaus_hip.so was built with -DMAUS_PANEL_CLOCK: run `make` in csrc/"
+
+
 def test_binding_loads_and_types_every_entry_point():
     from adaptive_matrix_solver_amd import _cabi
     lib = _cabi.load_library()
