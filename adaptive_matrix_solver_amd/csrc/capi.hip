@@ -1,6 +1,7 @@
 // libmaus_hip C ABI (include/maus_hip.h): context, device memory, stream, and the batched
 // phases of the MAUS candidate step.  Host orchestration stays in Python (ctypes).
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -8,6 +9,7 @@
 #include <vector>
 
 #include "ctx.h"
+#include <unistd.h>
 
 thread_local std::string g_err;
 
@@ -398,7 +400,20 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     if (c->info) { (void)hipFree(c->info); c->info = nullptr; }
     if (c->flags) { (void)hipFree(c->flags); c->flags = nullptr; }
     c->Hg = 0; c->Hbytes = 0;
-    HIPCHK(c, hipMalloc((void**)&c->H, per * G));
+    // The big allocation can fail although hipMemGetInfo just reported the room (memory of a process that has only just
+    // exited is handed back with a delay: seen with back-to-back bench runs on one box).  Wait a little, then make do
+    // with less -- batches beyond the workspace run in chunks -- rather than fail the step.
+    {
+        const int floor_g = std::min(G, std::max(32, round_up(std::min(want, 64), 32)));
+        int tries = 0;
+        while (hipMalloc((void**)&c->H, per * G) != hipSuccess) {
+            (void)hipGetLastError();
+            c->H = nullptr;
+            if (++tries <= 4) { usleep(250000); }
+            else if (G > floor_g) { G = std::max(floor_g, std::min(G - 32, (G * 3 / 4) / 32 * 32)); }
+            else FAIL(c, "LU workspace: hipMalloc failed even for the smallest batch (out of device memory)");
+        }
+    }
     HIPCHK(c, hipMalloc((void**)&c->ipiv, sizeof(int) * (size_t)G * npad));
     HIPCHK(c, hipMalloc((void**)&c->perm, sizeof(int) * (size_t)G * npad));
     HIPCHK(c, hipMalloc((void**)&c->mw_sync, maus_lu_mw_sync_bytes() * (size_t)G));
@@ -417,7 +432,7 @@ static LuWs make_ws(maus_ctx* c, int n, int G) {
     return w;
 }
 
-// up to three sub-batch streams, each sub-batch at least MAUS_LU_MIN_SUB (32) matrices (see maus_shifted_lu_solve)
+// up to three sub-batch streams, each sub-batch at least MAUS_LU_MIN_SUB (64) matrices (see maus_shifted_lu_solve)
 static int lu_stream_count() { const char* e = getenv("MAUS_LU_STREAMS"); int v = e ? atoi(e) : 3; return std::max(1, std::min(8, v)); }
 
 static int ensure_lu_streams(maus_ctx* c, int n) {
@@ -524,7 +539,7 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
     const int nchunks = (count + c->Hg - 1) / c->Hg;
     const int Gmax = (count + nchunks - 1) / nchunks;
     const int nst = lu_stream_count();
-    if (ensure_lu_streams(c, nst)) return -1;
+    if (ensure_lu_streams(c, std::max(nst, 3))) return -1;
     std::vector<int> h_info(Gmax), h_flags(Gmax);
     for (int off = 0; off < count; off += Gmax) {
         const int G = std::min(Gmax, count - off);
@@ -540,14 +555,39 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             HIPCHK(c, hipMemcpyAsync(c->Upert, (const double*)pert_data + 2 * (size_t)n * n * off, ub, hipMemcpyHostToDevice, c->st));
             dU = c->Upert;
         }
-        // Sub-batches on their own streams (at least 32 matrices each): the bandwidth- and latency-bound phases of one
-        // sub-batch (panel, triangular solves, H build) run beside the MFMA-bound trailing updates of the others.  The
-        // gain is bounded -- a streaming kernel beside the zgemm hides ~30 % of its time at best (tools/probe_corun.hip) --
-        // and more sub-batches mean smaller, less efficient launches: 1 / 2 / 3 / 4 / 6 streams gave 291 / 290 / 300 /
-        // 277 / 279 candidate-steps/s on the driver-shaped run (n=4096, 176-331 solves per step), and with the DMA zgemm a
-        // minimum sub-batch of 32 / 48 / 64 / 128 matrices 338.9 / 337.8 / 338.0 / 333.1.
-        static const int min_sub = [] { const char* e = getenv("MAUS_LU_MIN_SUB"); return e ? std::max(1, atoi(e)) : 32; }();
-        const int S = std::max(1, std::min(nst, G / min_sub));
+        // Sub-batches on their own streams: the bandwidth- and latency-bound phases of one sub-batch (panel, triangular
+        // solves, H build) run beside the MFMA-bound trailing updates of the others.  The gain is bounded -- a streaming
+        // kernel beside the zgemm hides ~30 % of its time at best (tools/probe_corun.hip) -- and more sub-batches mean
+        // smaller, less efficient launches.  How many pay depends on the batch size AND on the box: whole driver-shaped runs
+        // (n = 4096, pop = 256, 176-331 solves per step) gave 324.5 / 323.0 / 331.8 candidate-steps/s with 1 / 2 / 3 streams
+        // on one MI355X and 329.5 / 313.5 with 2 / 3 on another; at 139-165 solves per step two sub-batches beat three by
+        // 9 % (3.03 vs 3.30 ms per solve), at 79-109 two beat one by 2 %.  So the count is settled at run time, per
+        // batch-size class: the first calls of a class try the admissible counts once each (sub-batches of at least 32),
+        // the fastest per solve is kept.  Results do not depend on it (tests/test_gpu_bench_path.py: bit-equal).
+        // MAUS_LU_STREAMS=<n> (or MAUS_LU_TUNE=0) fixes the count instead: min(n, G / MAUS_LU_MIN_SUB).
+        static const int min_sub = [] { const char* e = getenv("MAUS_LU_MIN_SUB"); return e ? std::max(1, atoi(e)) : 64; }();
+        static const int tune_on = [] { const char* e = getenv("MAUS_LU_TUNE"); return e ? atoi(e) : 1; }();
+        int S, tune_cls = -1;
+        bool exploring = false;
+        if (getenv("MAUS_LU_STREAMS") || !tune_on) S = std::max(1, std::min(nst, G / min_sub));
+        else {
+            tune_cls = G >= 192 ? 2 : G >= 128 ? 1 : G >= 64 ? 0 : -1;
+            maus_ctx::LuTune& T = c->lu_tune;
+            if (tune_cls < 0) S = 1;
+            else if (T.choice[tune_cls]) S = T.choice[tune_cls];
+            else {
+                const int order[3] = {2, 3, 1};
+                const int smax = std::min(std::min(nst, 3), std::max(1, G / 32));
+                S = 0;
+                for (int o : order) if (o <= smax && !T.tried[tune_cls][o]) { S = o; break; }
+                if (S) exploring = true;
+                else {                                      // every admissible count tried: keep the fastest
+                    for (int o = 1; o <= 3; ++o) if (T.tried[tune_cls][o] && (!S || T.ms[tune_cls][o] < T.ms[tune_cls][S])) S = o;
+                    T.choice[tune_cls] = S = std::max(1, S);
+                }
+            }
+        }
+        const auto tune_t0 = std::chrono::steady_clock::now();
         if (S > 1) HIPCHK(c, hipEventRecord(c->ev_stage, c->st));
         std::vector<LuWs> wss;
         std::vector<int> los;
@@ -581,8 +621,18 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
         HIPCHK(c, hipMemcpyAsync(h_flags.data(), c->flags, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
         HIPCHK(c, hipGetLastError());
+        if (exploring) {
+            c->lu_tune.tried[tune_cls][S] = 1;
+            c->lu_tune.ms[tune_cls][S] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tune_t0).count() / G;
+        }
         finish_status(G, h_info.data(), h_flags.data(), status + off);
     }
+    return 0;
+}
+
+int maus_lu_stream_choice(maus_ctx* c, int* choice_out) {
+    if (!c || !choice_out) return -1;
+    for (int k = 0; k < 3; ++k) choice_out[k] = c->lu_tune.choice[k];
     return 0;
 }
 
