@@ -574,6 +574,7 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             tune_cls = G >= 192 ? 2 : G >= 128 ? 1 : G >= 64 ? 0 : -1;
             maus_ctx::LuTune& T = c->lu_tune;
             if (tune_cls < 0) S = 1;
+            else if (T.calls++ == 0) S = std::max(1, std::min(nst, G / min_sub));   // first call: one-off set-up costs (streams, jump polynomials) would be timed
             else if (T.choice[tune_cls]) S = T.choice[tune_cls];
             else {
                 const int order[3] = {2, 3, 1};

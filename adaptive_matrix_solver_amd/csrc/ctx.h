@@ -75,7 +75,7 @@ struct maus_ctx {
     std::vector<hipStream_t> lu_st; std::vector<hipEvent_t> lu_done; hipEvent_t ev_stage = nullptr;
     // Sub-batch stream count by batch-size class (64-127, 128-191, >= 192 solves), settled at run time: which count wins
     // differs from one MI355X box to the next (maus_shifted_lu_solve)
-    struct LuTune { int choice[3] = {0, 0, 0}; int tried[3][4] = {}; double ms[3][4] = {}; } lu_tune;
+    struct LuTune { int choice[3] = {0, 0, 0}; int tried[3][4] = {}; double ms[3][4] = {}; long calls = 0; } lu_tune;
     hipStream_t prof_st = nullptr;
     // history store (SURVEY f-4): rows appended on the device, oldest chunks spilled to host memory beyond a byte budget
     struct HistChunk { c128* dev = nullptr; c128* host = nullptr; long rows = 0; long cap = 0; };

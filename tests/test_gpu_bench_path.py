@@ -106,6 +106,49 @@ def test_eig4096_pop256_two_streams_against_host_and_lapack(ctx):
         assert np.linalg.norm(W[k] - x1[0]) <= 1e-11 * np.linalg.norm(ref), k
 
 
+def test_stream_count_settles_at_run_time_and_results_do_not_depend_on_it():
+    """The number of sub-batch streams is chosen at run time per batch-size class (the first calls of a class time the
+    admissible counts).  Whatever is tried or chosen, every call returns the same bits; the choice is reported."""
+    from adaptive_matrix_solver_amd import Context
+    from adaptive_matrix_solver_amd._cabi import PERT_MT19937
+    assert "MAUS_LU_STREAMS" not in os.environ and os.environ.get("MAUS_LU_TUNE", "1") != "0"
+    n, P = 160, 230
+    A = scenarios.ginibre(n, 77, None)
+    rng = np.random.default_rng(5)
+    V = (rng.standard_normal((P, n)) + 1j * rng.standard_normal((P, n))) / np.sqrt(n)
+    c = Context(0)
+    try:
+        c.set_matrix(A)
+        c.pop_reserve(P)
+        c.pop_put(0, list(range(P)), V)
+        lam = rng.standard_normal(P) + 1j * rng.standard_normal(P)
+        psi = np.full(P, 1e-20)
+        np.random.seed(9)
+        st = np.random.get_state()
+        outs = {}
+        for G in (230, 150, 100, 40):                       # classes >= 192, 128-191, 64-127, and below (always one stream)
+            sl = list(range(G))
+            desc = (st, 4 * n * n, 0, np.arange(G, dtype=np.int32))
+            for rep in range(6):
+                status = c.shifted_lu_solve(sl, lam[:G], psi[:G], 0, PERT_MT19937, desc)
+                assert (status == 0).all()
+                W = c.pop_get(2, sl, n)
+                if G in outs:
+                    assert np.array_equal(W, outs[G]), (G, rep)
+                outs[G] = W
+        choice = c.lu_stream_choice()
+        assert all(ch in (1, 2, 3) for ch in choice), choice
+        with _env(MAUS_LU_STREAMS=1):
+            for G in (230, 150, 100):
+                sl = list(range(G))
+                c.shifted_lu_solve(sl, lam[:G], psi[:G], 0, PERT_MT19937, (st, 4 * n * n, 0, np.arange(G, dtype=np.int32)))
+                assert np.array_equal(c.pop_get(2, sl, n), outs[G]), G
+        HW = outs[230] @ A.T - (lam - psi)[:, None] * outs[230]
+        assert np.linalg.norm(HW - V, axis=1).max() <= 1e-10 * np.linalg.norm(A, 1) * np.linalg.norm(outs[230], axis=1).max()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("n,count,cap", [(512, 200, 96), (160, 333, 128)])
 def test_chunked_batches_beyond_the_workspace(n, count, cap):
     """count > workspace capacity: balanced chunks, each split over the sub-batch streams; against numpy.linalg.solve."""
