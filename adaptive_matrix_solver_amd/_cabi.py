@@ -16,12 +16,16 @@ LIB_PATH = os.path.join(_HERE, "libmaus_hip.so")
 # every symbol include/maus_hip.h declares (tests/test_cabi_symbols.py checks the list against the header)
 SYMBOLS = [
     "maus_ctx_create", "maus_ctx_destroy", "maus_last_error", "maus_device_info", "maus_abi_version",
-    "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get", "maus_pop_copy", "maus_pop_device_ptr", "maus_hist_append", "maus_hist_get", "maus_hist_clear",
-    "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_lu_reserve", "maus_lu_workspace_allocs", "maus_lu_stream_choice", "maus_relax_normalise", "maus_residual",
+    "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get", "maus_pop_copy", "maus_pop_device_ptr", "maus_hist_append", "maus_hist_get", "maus_hist_clear", "maus_hist_generation",
+    "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_lu_reserve", "maus_lu_workspace_allocs", "maus_set_shared_device", "maus_lu_mw_aborts", "maus_lu_stream_choice", "maus_relax_normalise", "maus_residual",
     "maus_svd_power_step", "maus_set_eigvecs", "maus_herm_match", "maus_gmres", "maus_gmres_pert", "maus_jacobi_check",
     "maus_profile_union_ms", "maus_gram", "maus_zgemm_host", "maus_zgemm_bench", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
     "maus_profile_enable", "maus_profile_read", "maus_sync", "maus_mt19937_jump",
+    "maus_device_count", "maus_comm_unique_id", "maus_comm_init", "maus_comm_destroy", "maus_comm_info",
+    "maus_comm_allgather_records", "maus_comm_allgather_rows", "maus_comm_bcast", "maus_comm_bcast_eigvecs", "maus_comm_stats",
 ]
+
+COMM_ID_BYTES = 128
 
 POP_X, POP_U, POP_W, POP_Y = 0, 1, 2, 3
 KIND_EIG, KIND_LINEAR, KIND_SVD = 1, 2, 3
@@ -73,10 +77,13 @@ def load_library():
         "maus_hist_append": ([vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_int64)], C.c_int),
         "maus_hist_get": ([vp, vp, C.c_int, C.c_int, vp], C.c_int),
         "maus_hist_clear": ([vp], C.c_int),
+        "maus_hist_generation": ([vp], C.c_int64),
         "maus_matvec_rayleigh": ([vp, vp, C.c_int, vp, vp], C.c_int),
         "maus_shifted_lu_solve": ([vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp], C.c_int),
         "maus_lu_reserve": ([vp, C.c_int, C.c_int, ip], C.c_int),
         "maus_lu_workspace_allocs": ([vp], C.c_int),
+        "maus_set_shared_device": ([vp, C.c_int], C.c_int),
+        "maus_lu_mw_aborts": ([vp], C.c_int),
         "maus_lu_stream_choice": ([vp, C.POINTER(C.c_int)], C.c_int),
         "maus_relax_normalise": ([vp, vp, C.c_int, vp, C.c_int, vp], C.c_int),
         "maus_residual": ([vp, C.c_int, vp, C.c_int, vp, vp, vp], C.c_int),
@@ -97,6 +104,16 @@ def load_library():
         "maus_profile_read": ([vp, C.c_int, ip, dp, dp, dp], C.c_int),
         "maus_sync": ([vp], C.c_int),
         "maus_mt19937_jump": ([vp, i32p, C.c_uint64], C.c_int),
+        "maus_device_count": ([], C.c_int),
+        "maus_comm_unique_id": ([C.c_char_p], C.c_int),
+        "maus_comm_init": ([vp, C.c_int, C.c_int, C.c_char_p], C.c_int),
+        "maus_comm_destroy": ([vp], C.c_int),
+        "maus_comm_info": ([vp, ip, ip], C.c_int),
+        "maus_comm_allgather_records": ([vp, vp, C.c_size_t, vp], C.c_int),
+        "maus_comm_allgather_rows": ([vp, C.c_int, vp, vp, C.c_int], C.c_int),
+        "maus_comm_bcast": ([vp, vp, C.c_size_t, C.c_int], C.c_int),
+        "maus_comm_bcast_eigvecs": ([vp, C.c_int, C.c_int], C.c_int),
+        "maus_comm_stats": ([vp, C.POINTER(C.c_long), dp, dp, C.c_int], C.c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)          # AttributeError here == missing export: fail loudly
@@ -115,6 +132,13 @@ def _c128(a, shape=None):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class _ClosedLib:
+    """Stands in for the library handle of a closed Context: any call raises instead of handing a NULL context to C."""
+
+    def __getattr__(self, name):
+        raise MausHipError(f"{name}: the context has been closed")
 
 
 class Context:
@@ -136,6 +160,7 @@ class Context:
         if getattr(self, "h", None):
             self.lib.maus_ctx_destroy(self.h)
             self.h = None
+            self.lib = _ClosedLib()
 
     def __del__(self):
         try:
@@ -144,6 +169,8 @@ class Context:
             pass
 
     def _ck(self, rc, what):
+        if not getattr(self, "h", None):
+            raise MausHipError(f"{what}: the context has been closed")
         if rc != 0:
             msg = self.lib.maus_last_error(self.h)
             raise MausHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
@@ -182,6 +209,15 @@ class Context:
 
     def lu_workspace_allocations(self) -> int:
         return int(self.lib.maus_lu_workspace_allocs(self.h))
+
+    def set_shared_device(self, shared=True):
+        """Tell the library that other processes use this GPU too (ranks of a gloo rehearsal on one device): kernels that
+        need every one of their workgroups resident at once (the multi-workgroup LU panel) are then never used."""
+        self._ck(self.lib.maus_set_shared_device(self.h, 1 if shared else 0), "maus_set_shared_device")
+
+    def lu_mw_aborts(self) -> int:
+        """Batches that were repeated with one panel workgroup per matrix after a rendezvous time-out."""
+        return int(self.lib.maus_lu_mw_aborts(self.h))
 
     def lu_stream_choice(self):
         """Sub-batch stream counts settled on for calls of 64-127, 128-191 and >= 192 solves (0: not settled yet)."""
@@ -254,6 +290,11 @@ class Context:
 
     def hist_clear(self):
         self._ck(self.lib.maus_hist_clear(self.h), "maus_hist_clear")
+
+    def hist_generation(self) -> int:
+        if not getattr(self, "h", None):
+            raise MausHipError("maus_hist_generation: the context has been closed")
+        return int(self.lib.maus_hist_generation(self.h))
 
     # -- phases --------------------------------------------------------------
     def matvec_rayleigh(self, slots):
@@ -374,6 +415,40 @@ class Context:
         self._ck(self.lib.maus_jacobi_check(self.h, k, _ptr(sh), _ptr(ps), _ptr(ok)), "maus_jacobi_check")
         return ok.astype(bool)
 
+    # -- population sharding: RCCL collectives on this context's stream (csrc/comm.hip) -----------------------------
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._ck(self.lib.maus_comm_init(self.h, int(rank), int(world), unique_id), "maus_comm_init")
+
+    def comm_destroy(self):
+        self._ck(self.lib.maus_comm_destroy(self.h), "maus_comm_destroy")
+
+    def comm_allgather_records(self, send: np.ndarray, world: int) -> np.ndarray:
+        """send: C-contiguous array (any dtype) of the same shape on every rank -> array of shape (world,) + send.shape."""
+        send = np.ascontiguousarray(send)
+        out = np.empty((world,) + send.shape, dtype=send.dtype)
+        self._ck(self.lib.maus_comm_allgather_records(self.h, _ptr(send), send.nbytes, _ptr(out)), "maus_comm_allgather_records")
+        return out
+
+    def comm_allgather_rows(self, which, slots_by_rank, length):
+        counts = np.ascontiguousarray([len(s) for s in slots_by_rank], dtype=np.int32)
+        flat = np.ascontiguousarray([s for sl in slots_by_rank for s in sl], dtype=np.int32)
+        self._ck(self.lib.maus_comm_allgather_rows(self.h, int(which), _ptr(flat), _ptr(counts), int(length)), "maus_comm_allgather_rows")
+
+    def comm_bcast(self, arr: np.ndarray, root=0):
+        """In-place broadcast of a C-contiguous array (same shape / dtype on every rank)."""
+        assert arr.flags["C_CONTIGUOUS"]
+        self._ck(self.lib.maus_comm_bcast(self.h, _ptr(arr), arr.nbytes, int(root)), "maus_comm_bcast")
+        return arr
+
+    def comm_bcast_eigvecs(self, n, root=0):
+        self._ck(self.lib.maus_comm_bcast_eigvecs(self.h, int(n), int(root)), "maus_comm_bcast_eigvecs")
+
+    def comm_stats(self, reset=False):
+        calls, by, ms = C.c_long(), C.c_double(), C.c_double()
+        self._ck(self.lib.maus_comm_stats(self.h, C.byref(calls), C.byref(by), C.byref(ms), 1 if reset else 0), "maus_comm_stats")
+        return {"collectives": int(calls.value), "bytes": float(by.value), "ms": float(ms.value)}
+
     # -- test / utility entry points ------------------------------------------
     def zgemm(self, A, B, C_in=None, b_layout=0, conj_a=False, conj_b=False, alpha=1.0, beta=0):
         A = _c128(A)
@@ -402,6 +477,21 @@ class Context:
         ipiv = np.zeros((cnt, n), dtype=np.int32) if want_ipiv else None
         self._ck(self.lib.maus_lu_solve_host(self.h, cnt, n, _ptr(A), _ptr(b), _ptr(x), _ptr(status), _ptr(ipiv)), "maus_lu_solve_host")
         return (x, status, ipiv) if want_ipiv else (x, status)
+
+
+def device_count() -> int:
+    """HIP devices visible to this process (0 on a box without a GPU)."""
+    return int(load_library().maus_device_count())
+
+
+def comm_unique_id() -> bytes:
+    """A fresh RCCL unique id (one rank creates it, every rank passes it to Context.comm_init)."""
+    lib = load_library()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    if lib.maus_comm_unique_id(buf) != 0:
+        msg = lib.maus_last_error(None)
+        raise MausHipError(f"maus_comm_unique_id failed: {msg.decode() if msg else ''}")
+    return buf.raw
 
 
 def mt19937_jump(key: np.ndarray, pos: int, nwords: int):

@@ -114,6 +114,7 @@ int maus_ctx_destroy(maus_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
+    (void)maus_comm_destroy(c);
     void* ptrs[] = {c->A, c->b, c->V, c->X, c->U, c->W, c->Y, c->d_slots, c->d_i1, c->d_i2, c->d_c1, c->d_c2, c->d_r1, c->d_r2,
                     c->H, c->ipiv, c->perm, c->mw_sync, c->info, c->flags, c->Upert, c->scratch};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -285,10 +286,13 @@ __global__ void hist_append_kernel(c128* __restrict__ dst, long len, const c128*
 
 static void hist_free(maus_ctx* c) {
     for (auto& h : c->hist) { if (h.dev) (void)hipFree(h.dev); if (h.host) free(h.host); }
+    if (!c->hist.empty() || c->hist_rows) c->hist_gen++;
     c->hist.clear(); c->hist_len = 0; c->hist_rows = 0; c->hist_dev_bytes = 0;
 }
 
 int maus_hist_clear(maus_ctx* c) { HIPCHK(c, hipStreamSynchronize(c->st)); hist_free(c); return 0; }
+
+int64_t maus_hist_generation(maus_ctx* c) { return c ? (int64_t)c->hist_gen : -1; }
 
 int maus_hist_append(maus_ctx* c, int which, const int* slots, int count, int len, int64_t* first_index_out) {
     c128* P = pop_array(c, which);
@@ -380,7 +384,8 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     int npad = round_up(n, 32);
     if (npad > maus_lu_max_npad()) FAIL(c, "direct LU path supports n <= 8192 in this build");
     size_t per = 2 * sizeof(c128) * (size_t)npad * (npad + 32);    // H and the logical-order U array (implicit pivoting)
-    if (c->H && c->Hnpad == npad && c->Hg >= want) return 0;
+    if (c->H && c->Hnpad == npad && (c->Hg >= want || c->ws_at_limit)) return 0;     // at the limit: callers chunk
+    const bool second = c->H && c->Hnpad == npad;
     size_t fr = 0, tot = 0;
     HIPCHK(c, hipMemGetInfo(&fr, &tot));
     if (c->H) fr += c->Hbytes;
@@ -390,7 +395,7 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     int G = round_up(want, 32);
     if (c->H && c->Hnpad == npad) G = std::max(G, cap);               // a second allocation goes straight to the limit: never a third
     G = std::min(std::min(G, cap), gmax);
-    if (c->H && c->Hnpad == npad && c->Hg >= G) return 0;
+    if (c->H && c->Hnpad == npad && c->Hg >= G) { c->ws_at_limit = true; return 0; }   // nothing more to be had
     HIPCHK(c, hipStreamSynchronize(c->st));
     for (auto st : c->lu_st) HIPCHK(c, hipStreamSynchronize(st));
     if (c->H) { (void)hipFree(c->H); c->H = nullptr; }
@@ -399,7 +404,8 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     if (c->mw_sync) { (void)hipFree(c->mw_sync); c->mw_sync = nullptr; }
     if (c->info) { (void)hipFree(c->info); c->info = nullptr; }
     if (c->flags) { (void)hipFree(c->flags); c->flags = nullptr; }
-    c->Hg = 0; c->Hbytes = 0;
+    c->Hg = 0; c->Hbytes = 0; c->ws_at_limit = false;
+    const int G_asked = G;
     // The big allocation can fail although hipMemGetInfo just reported the room (memory of a process that has only just
     // exited is handed back with a delay: seen with back-to-back bench runs on one box).  Wait a little, then make do
     // with less -- batches beyond the workspace run in chunks -- rather than fail the step.
@@ -421,6 +427,10 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     HIPCHK(c, hipMalloc((void**)&c->flags, sizeof(int) * G));
     c->Hbytes = per * G; c->Hg = G; c->Hnpad = npad;
     c->ws_allocs++;
+    // A second allocation for this matrix size, one that hit the cap, or one that had to make do with less than it asked
+    // for is final: hipMemGetInfo over-reports right after another process has exited, so asking again would free and
+    // re-map the whole workspace (seconds, inside somebody's step) for nothing.  Larger batches run in chunks.
+    c->ws_at_limit = second || G < G_asked || G >= std::min(cap, gmax);
     return 0;
 }
 
@@ -455,6 +465,13 @@ static int ensure_lu_streams(maus_ctx* c, int n) {
 
 static int lu_nbo() { const char* e = getenv("MAUS_LU_NBO"); int v = e ? atoi(e) : 512; if (v < 32) v = 32; return (v / 32) * 32; }
 
+// info < 0 is never a numerical outcome: INT_MIN is written by the multi-workgroup panel when a rendezvous between the
+// workgroups of one matrix timed out (lu.hip) -- that matrix is then half factored and its "solution" is garbage.
+static bool any_internal_failure(int G, const int* info) {
+    for (int g = 0; g < G; ++g) if (info[g] < 0) return true;
+    return false;
+}
+
 static void finish_status(int G, const int* info, const int* flags, int32_t* status) {
     for (int g = 0; g < G; ++g) {
         if (flags[g] & 1) status[g] = -1;
@@ -462,6 +479,13 @@ static void finish_status(int G, const int* info, const int* flags, int32_t* sta
         else if (flags[g] & 2) status[g] = -2;
         else status[g] = 0;
     }
+}
+
+static bool mw_allowed(const maus_ctx* c) { return !c->shared_device && !c->mw_disabled; }
+static void mw_configure(const maus_ctx* c, LuWs& w) {
+    w.mw_sync = mw_allowed(c) ? c->mw_sync : nullptr;
+    const char* e = getenv("MAUS_PANEL_MW_FORCE_ABORT");          // test hook: see lu_panel_mw_kernel
+    if (e && atoi(e)) { w.mw_force_abort = 1; w.mw_timeout = 2000000ull; }   // 20 ms instead of 2 s
 }
 
 
@@ -546,8 +570,6 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
         HIPCHK(c, hipMemcpyAsync(c->d_slots, slots + off, sizeof(int) * G, hipMemcpyHostToDevice, c->st));
         HIPCHK(c, hipMemcpyAsync(c->d_c1, shift + 2 * (size_t)off, sizeof(c128) * G, hipMemcpyHostToDevice, c->st));
         HIPCHK(c, hipMemcpyAsync(c->d_r1, psi + off, sizeof(double) * G, hipMemcpyHostToDevice, c->st));
-        HIPCHK(c, hipMemsetAsync(c->info, 0, sizeof(int) * G, c->st));
-        HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int) * G, c->st));
         const double* dU = nullptr;
         if (pert_mode == MAUS_PERT_UNIFORM) {
             size_t ub = sizeof(double) * 2 * (size_t)n * n * G;
@@ -588,6 +610,12 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
                 }
             }
         }
+        // One more pass without the multi-workgroup panel if a rendezvous of it timed out (info = INT_MIN): its premise --
+        // all workgroups of a matrix resident at once -- does not hold on a device that somebody else is using too.  The
+        // pass rebuilds H from the same inputs, so the results are those of a context that never used that kernel.
+        for (int pass = 0; pass < 2; ++pass) {
+        HIPCHK(c, hipMemsetAsync(c->info, 0, sizeof(int) * G, c->st));
+        HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int) * G, c->st));
         const auto tune_t0 = std::chrono::steady_clock::now();
         if (S > 1) HIPCHK(c, hipEventRecord(c->ev_stage, c->st));
         std::vector<LuWs> wss;
@@ -599,7 +627,7 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             if (S > 1) HIPCHK(c, hipStreamWaitEvent(st, c->ev_stage, 0));
             LuWs w = make_ws(c, n, g);
             w.H += (long)lo * w.strideH; w.U += (long)lo * w.strideH; w.perm += (long)lo * w.npad; w.ipiv += (long)lo * w.npad; w.info += lo; w.flags += lo; w.st = st;
-            if (S == 1) w.mw_sync = c->mw_sync;          // the only LU in flight on this device: the panel may spread over several workgroups per matrix
+            if (S == 1) mw_configure(c, w);              // the only LU in flight on this device: the panel may spread over several workgroups per matrix
             c->prof_st = st;
             if (pert_mode == MAUS_PERT_MT19937) {
                 if (mt_prepare_and_build(c, w, (const maus_mt_desc*)pert_data, off + lo, g, rhs_mode, lo, sb)) return -1;
@@ -622,10 +650,16 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
         HIPCHK(c, hipMemcpyAsync(h_flags.data(), c->flags, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
         HIPCHK(c, hipGetLastError());
-        if (exploring) {
+        if (any_internal_failure(G, h_info.data())) {
+            if (pass == 0 && !c->mw_disabled) { c->mw_disabled = true; c->mw_aborts++; continue; }
+            FAIL(c, "maus_shifted_lu_solve: internal error: LU panel rendezvous timed out (info < 0) and the batch could not be repeated");
+        }
+        if (exploring && pass == 0) {
             c->lu_tune.tried[tune_cls][S] = 1;
             c->lu_tune.ms[tune_cls][S] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tune_t0).count() / G;
         }
+        break;
+        }   // pass
         finish_status(G, h_info.data(), h_flags.data(), status + off);
     }
     return 0;
@@ -647,10 +681,11 @@ int maus_lu_solve_host(maus_ctx* c, int count, int n, const double* a, const dou
     std::vector<int> h_info(Gmax), h_flags(Gmax);
     for (int off = 0; off < count; off += Gmax) {
         const int G = std::min(Gmax, count - off);
-        LuWs w = make_ws(c, n, G);
-        w.mw_sync = c->mw_sync;
         HIPCHK(c, hipMemcpyAsync(dA, a + 2 * (size_t)n * n * off, ab * G, hipMemcpyHostToDevice, c->st));
         HIPCHK(c, hipMemcpyAsync(dB, b + 2 * (size_t)n * off, bb * G, hipMemcpyHostToDevice, c->st));
+        for (int pass = 0; pass < 2; ++pass) {
+        LuWs w = make_ws(c, n, G);
+        mw_configure(c, w);
         HIPCHK(c, hipMemsetAsync(c->info, 0, sizeof(int) * G, c->st));
         HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int) * G, c->st));
         maus_load_h(w, dA, dB);
@@ -665,6 +700,12 @@ int maus_lu_solve_host(maus_ctx* c, int count, int n, const double* a, const dou
         }
         HIPCHK(c, hipStreamSynchronize(c->st));
         HIPCHK(c, hipGetLastError());
+        if (any_internal_failure(G, h_info.data())) {                 // see maus_shifted_lu_solve
+            if (pass == 0 && !c->mw_disabled) { c->mw_disabled = true; c->mw_aborts++; continue; }
+            FAIL(c, "maus_lu_solve_host: internal error: LU panel rendezvous timed out (info < 0) and the batch could not be repeated");
+        }
+        break;
+        }   // pass
         finish_status(G, h_info.data(), h_flags.data(), status + off);
     }
     return 0;
@@ -678,6 +719,10 @@ int maus_lu_reserve(maus_ctx* c, int n, int count, int* capacity_out) {
 }
 
 int maus_lu_workspace_allocs(maus_ctx* c) { return c ? c->ws_allocs : -1; }
+
+int maus_set_shared_device(maus_ctx* c, int shared) { if (!c) return -1; c->shared_device = shared != 0; return 0; }
+
+int maus_lu_mw_aborts(maus_ctx* c) { return c ? c->mw_aborts : -1; }
 
 int maus_relax_normalise(maus_ctx* c, const int* slots, int count, const double* alpha, int normalise, double* norm_out) {
     if (!c->X) FAIL(c, "maus_relax_normalise: population missing");

@@ -61,6 +61,10 @@ struct maus_ctx {
     double *d_r1 = nullptr, *d_r2 = nullptr;
     // LU workspace
     c128* H = nullptr; size_t Hbytes = 0; int Hg = 0; int Hnpad = 0; int ws_allocs = 0;
+    bool ws_at_limit = false;      // the workspace has reached what this device / MAUS_LU_BATCH allow: never re-allocated again for this npad
+    // multi-workgroup panel (lu.hip): off when the device is shared with other processes (maus_set_shared_device) and
+    // after its first rendezvous time-out on this context; mw_aborts counts the batches that were repeated without it
+    bool shared_device = false; bool mw_disabled = false; int mw_aborts = 0;
     int *ipiv = nullptr, *perm = nullptr, *info = nullptr, *flags = nullptr; void* mw_sync = nullptr;
     double* Upert = nullptr; size_t Ubytes = 0;
     // device-side MT19937 regeneration (mtdev.hip)
@@ -80,6 +84,12 @@ struct maus_ctx {
     // history store (SURVEY f-4): rows appended on the device, oldest chunks spilled to host memory beyond a byte budget
     struct HistChunk { c128* dev = nullptr; c128* host = nullptr; long rows = 0; long cap = 0; };
     std::vector<HistChunk> hist; long hist_len = 0; long hist_rows = 0; size_t hist_dev_bytes = 0;
+    long hist_gen = 0;             // bumped whenever the store is dropped: indices handed out before are stale
+    // population sharding (comm.hip): one RCCL communicator per context, a staging buffer, and the host wall time spent
+    // inside collectives (reported per rank by bench.py)
+    void* comm = nullptr; int comm_rank = 0, comm_world = 0;
+    void* comm_buf = nullptr; size_t comm_buf_bytes = 0;
+    long comm_calls = 0; double comm_bytes = 0, comm_ms = 0;
     // generic scratch (host-GEMM / host-LU test entry points, GMRES)
     void* scratch = nullptr; size_t scratch_bytes = 0;
     // measurement

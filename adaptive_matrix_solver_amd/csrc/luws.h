@@ -8,6 +8,11 @@ struct LuWs {
     // U (and the carried right-hand side) are written in LOGICAL order to the second array U (same ld / stride as H)
     c128* U; int* perm;
     void* mw_sync = nullptr;     // per-matrix rendezvous area of the multi-workgroup panel; null unless this LU is alone on the device
+    // multi-workgroup panel: how long a rendezvous may wait (100 MHz ticks) before the matrix is reported as
+    // info = INT_MIN (the caller then repeats the batch with one workgroup per matrix), and the test hook that makes one
+    // workgroup skip an arrival (MAUS_PANEL_MW_FORCE_ABORT)
+    unsigned long long mw_timeout = 200000000ull;
+    int mw_force_abort = 0;
     int* ipiv; int* info; int* flags;
     hipStream_t st;
     void (*tick)(void* ud, int klass, int phase, double flops, double bytes); void* ud;

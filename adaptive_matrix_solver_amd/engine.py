@@ -161,6 +161,10 @@ class DeviceEngine:
         self.pert_mode = pert_mode              # 'auto' | 'uniform' | 'mt19937' | 'none'
         self.gmres_compat = gmres_compat        # 'rtol' | 'scipy-legacy'  
         self.comm = comm                        # dist.PopulationComm or None
+        if comm is not None and not getattr(comm, "on_device", False) and hasattr(self.ctx, "set_shared_device"):
+            # host-side collectives (gloo): several ranks may be rehearsing on ONE GPU, so kernels whose workgroups wait
+            # for each other (multi-workgroup LU panel) must not assume they have the device to themselves
+            self.ctx.set_shared_device(True)
         self._bound = None                      # matrix object currently on the device
         self._bound_b = None
         self._eig_cache = None                  # (matrix obj, evals) for the Hermitian shortcut
@@ -527,6 +531,16 @@ class DeviceEngine:
                     c.residual_k = strat.get("current_convergence_threshold", 1e-6) * 0.1
                     c.state = S.CONVERGED
                     c.stuck_counter = 0
+                    # AMS:246-247: a collapsed u_k / right_v_k is replaced by ones/sqrt(dim).  ||u_k|| is norms[k, 2]
+                    # (a collapse there has already left through the exception path, like AMS:236-239 raises before
+                    # these lines); right_v_k = s / (sigma2 if sigma2 > 1e-10 else 1), so its norm is below 1e-10
+                    # exactly when sigma2 is.  Reachable only at a rounding knife edge.
+                    if norms[k, 2] < 1e-10:
+                        c.u_k = np.ones(c.M_rows, dtype=np.complex128) / np.sqrt(c.M_rows)
+                        c._push(force=True)
+                    if norms[k, 3] < 1e-10:
+                        c.right_v_k = np.ones(c.M_cols, dtype=np.complex128) / np.sqrt(c.M_cols)
+                        c._push(force=True)
                 else:
                     c.stuck_counter = max(0, c.stuck_counter - 1)
             if ev is None:

@@ -178,13 +178,22 @@ class InverseIterateSolver:
 
 
 class _HistRef:
-    """One recorded iterate whose vectors live in the context's history store (device, spilled to host when old)."""
-    __slots__ = ("ctx", "scalar", "rows")
+    """One recorded iterate whose vectors live in the context's history store (device, spilled to host when old).
+    The store is dropped when the context is rebound to a matrix with another vector length (engine reuse) or cleared;
+    the reference records the store's generation so that a stale index is refused instead of resolving to the rows
+    of whoever appended next."""
+    __slots__ = ("ctx", "scalar", "rows", "gen")
 
     def __init__(self, ctx, scalar, rows):
         self.ctx, self.scalar, self.rows = ctx, scalar, rows          # rows: ((history index, length), ...)
+        self.gen = ctx.hist_generation() if hasattr(ctx, "hist_generation") else 0
 
     def resolve(self):
+        if hasattr(self.ctx, "hist_generation") and self.ctx.hist_generation() != self.gen:
+            raise RuntimeError("param_history entry refers to a device history store that has since been dropped "
+                               "(the engine was rebound to a matrix of another size, or hist_clear() was called); "
+                               "read param_history before reusing the engine, or construct candidates with a host history "
+                               "(n <= 512)")
         vecs = tuple(self.ctx.hist_get([ix], ln)[0] for ix, ln in self.rows)
         return vecs if self.scalar is None else (self.scalar,) + vecs
 

@@ -105,6 +105,10 @@ int maus_pop_copy(maus_ctx* ctx, int which_dst, int which_src, const int* slots,
 int maus_hist_append(maus_ctx* ctx, int which, const int* slots, int count, int len, int64_t* first_index_out);
 int maus_hist_get(maus_ctx* ctx, const int64_t* indices, int count, int len, double* host_c128);
 int maus_hist_clear(maus_ctx* ctx);
+/* Generation of the history store: incremented whenever the store is dropped (maus_hist_clear, maus_set_matrix with a
+ * different vector length).  A caller that keeps row indices (solver._HistRef) records the generation with them and
+ * refuses to resolve an index of an older generation instead of reading somebody else's rows. */
+int64_t maus_hist_generation(maus_ctx* ctx);
 
 /* ---- phases of update_solution_step, batched over `count` candidates ---- */
 /* Y[slot] = A @ X[slot]; num = vdot(v, A@v), den = vdot(v, v)      AMS:264-268.
@@ -135,6 +139,19 @@ int maus_lu_reserve(maus_ctx* ctx, int n, int count, int* capacity_out);
 /* Number of times the LU workspace has been (re-)allocated on this context (measurement: a timed region must not
  * contain one). */
 int maus_lu_workspace_allocs(maus_ctx* ctx);
+
+/* Robustness of the small-batch panel (no reference counterpart; the reference contract it protects is that every failed
+ * solve surfaces to the retry ladder, AMS:94-104).  For batches that run on one stream the base panel of the LU may
+ * spread over several workgroups per matrix that rendezvous once per pivot column; that needs all of them resident
+ * at once, which holds only while this context has the device to itself.
+ *  - maus_set_shared_device(ctx, 1): the caller knows the device is shared with other processes (several ranks of a
+ *    `gloo` rehearsal on one GPU): the multi-workgroup panel is never used.
+ *  - A rendezvous that times out marks the matrix (LAPACK-style info = INT_MIN).  The library then repeats the whole
+ *    batch with one workgroup per matrix, switches the multi-workgroup panel off for the rest of the context's life and
+ *    counts the event (maus_lu_mw_aborts).  If the repeat fails too the call returns -1 (maus_last_error: "LU panel
+ *    rendezvous timed out"): a half-factored matrix is never reported as status 0. */
+int maus_set_shared_device(maus_ctx* ctx, int shared);
+int maus_lu_mw_aborts(maus_ctx* ctx);
 
 /* Sub-batch stream counts this context settled on for calls of 64-127, 128-191 and >= 192 solves (choice_out[3]; 0 = not
  * settled yet).  maus_shifted_lu_solve splits a large batch into independent sub-batches on their own streams; which
@@ -197,6 +214,37 @@ int maus_gmres_pert(maus_ctx* ctx, const int* slots, int count, const double* sh
                     int32_t* info_out, int32_t* inner_out, int32_t* status, int32_t* jacobi_out);
 /* AMS:67-72 gate: ok[i]=1 iff all 1/diag(H_k) finite and all |diag(H_k)| > 1e-12 */
 int maus_jacobi_check(maus_ctx* ctx, int count, const double* shift_c128, const double* psi, int32_t* ok);
+
+/* ---- population sharding over the GPUs of one node: RCCL over xGMI ------------------------------------------------
+ * No reference counterpart: AMS:574-576 steps the candidates in one sequential loop.  Within an iteration a candidate's
+ * step reads only (A, b, strategy) and its own state (AMS:576), so one process per GPU steps a contiguous block of the
+ * active candidates and the only exchange is an all-gather -- of the per-candidate scalar records the host bookkeeping
+ * consumes (AMS:424-475, 504-549: residual, stuckness, weight, status ...) and of the rows the owners updated.  librccl is
+ * loaded on first use (dlopen); a process that never shards never needs it.  All calls are collective: every rank of
+ * the communicator makes the same call with the same sizes.
+ *   maus_device_count        HIP devices visible to this process (0 without a GPU; never fails).
+ *   maus_comm_unique_id      ONE rank creates the 128-byte id (ncclGetUniqueId) and hands it to the others by any means
+ *                            (dist.py: a socket on MASTER_ADDR).
+ *   maus_comm_init           ncclCommInitRank on the context's device; one communicator per context.
+ *   maus_comm_allgather_records   host buffers: recv[r] <- rank r's send (bytes_per_rank each), rank order.
+ *   maus_comm_allgather_rows      device to device on population array `which`: slots[] lists the slots of every stepped
+ *                            candidate grouped by owner rank (counts[r] per rank, the same list on every rank); on return
+ *                            every rank holds every owner's rows.
+ *   maus_comm_bcast          host buffer from `root` to all (start-up diagnostics, eigenvalues: computed by rank 0 only).
+ *   maus_comm_bcast_eigvecs  the eigenvector matrix of the Hermitian shortcut (AMS:161; maus_set_eigvecs on `root` only),
+ *                            device to device.
+ *   maus_comm_stats          collectives issued, payload bytes, host wall ms inside them (reset != 0 zeroes them). */
+#define MAUS_COMM_ID_BYTES 128
+int maus_device_count(void);
+int maus_comm_unique_id(char* id_out /* MAUS_COMM_ID_BYTES */);
+int maus_comm_init(maus_ctx* ctx, int rank, int world, const char* id /* MAUS_COMM_ID_BYTES */);
+int maus_comm_destroy(maus_ctx* ctx);
+int maus_comm_info(maus_ctx* ctx, int* rank_out, int* world_out);
+int maus_comm_allgather_records(maus_ctx* ctx, const void* send, size_t bytes_per_rank, void* recv);
+int maus_comm_allgather_rows(maus_ctx* ctx, int which, const int* slots, const int* counts, int len);
+int maus_comm_bcast(maus_ctx* ctx, void* host_buf, size_t bytes, int root);
+int maus_comm_bcast_eigvecs(maus_ctx* ctx, int n, int root);
+int maus_comm_stats(maus_ctx* ctx, long* calls_out, double* bytes_out, double* ms_out, int reset);
 
 /* ---- plain batched GEMM on the context's stream (tests, Gram blocks) ----- */
 /* C[M,N] = alpha * opA(A)[M,K] * opB(B) + beta * C, host in/out, row-major complex128.

@@ -75,6 +75,10 @@ TRAJECTORIES = {
     "herm64":  dict(kind="eig", build=("hermitian", 64, 64), P=16, iters=3, seed=5, tol=1e-8),
     "svd5x4":  dict(kind="svd", build=("svd", 5, 4, 21, -3.0), P=25, iters=30, seed=11, tol=1e-6),
     "svd64":   dict(kind="svd", build=("svd", 64, 48, 22, -8.0), P=40, iters=20, seed=11, tol=1e-8),
+    # AMS:243-247: A = 1e-10 * (a dense unitary) puts ||A v|| and ||A^H u|| on the 1e-10 knife edge of AMS:235 / AMS:242,
+    # so that the tiny-sigma convergence branch is taken with a right vector that was left un-normalised (norm < 1e-10)
+    # and is replaced by ones/sqrt(n) (AMS:247: 18 times in this run); the collapse branches AMS:236-239 fire too (17 times)
+    "svdtiny": dict(kind="svd", build=("scaled_unitary", 6, 3, 1e-10), P=12, iters=4, seed=1, tol=1e-8),
     # G7: linear systems -- stable/direct, and Fragile (GMRES preferred -> LU fallback under SciPy>=1.14)
     "lin24":   dict(kind="lin", build=("ginibre_b", 24, 24), P=10, iters=12, seed=3, tol=1e-8),
     "lin32f":  dict(kind="lin", build=("widediag", 32, 32, 7.0), P=10, iters=8, seed=3, tol=1e-8),
@@ -98,6 +102,10 @@ def build(spec):
         return prescribed_svd(b[1], b[2], b[3], b[4]), None
     if b[0] == "widediag":
         return wide_diag_system(b[1], b[2], b[3])
+    if b[0] == "scaled_unitary":
+        rng = np.random.default_rng(b[2])
+        Q, _ = np.linalg.qr(rng.standard_normal((b[1], b[1])) + 1j * rng.standard_normal((b[1], b[1])))
+        return (b[3] * Q).astype(np.complex128), None
     raise KeyError(b[0])
 
 

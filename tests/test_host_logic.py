@@ -51,7 +51,7 @@ def versions_match(rec):
 
 # (the Hermitian scenarios are bit-exact too: eigh is computed once per matrix instead of once per
 # candidate, but it is the same LAPACK call on the same input, so (lambda, V) are identical)
-@pytest.mark.parametrize("name", ["eig16", "eig64", "eig48u", "lap8", "lin24", "lin32f", "svd5x4", "svd64",
+@pytest.mark.parametrize("name", ["eig16", "eig64", "eig48u", "lap8", "lin24", "lin32f", "svd5x4", "svd64", "svdtiny",
                                   "herm16", "herm64", "lap8h"])
 def test_host_logic_bit_exact_vs_reference_fixtures(name):
     with open(os.path.join(GOLD, f"traj_{name}.json")) as f:
