@@ -1,39 +1,152 @@
-"""Population sharding across the GPUs of one node (one process per GPU, torch.distributed).
+"""Population sharding across the GPUs of one node (one process per GPU).
 
-The candidate step has no candidate<->candidate data flow: within an iteration
-every candidate reads (A, b, strategy) and its own state.  So the active candidates are
-block-partitioned over the ranks, every rank runs the batched HIP phases for its block only,
-and the per-candidate scalar records the host bookkeeping needs (Rayleigh dots, solve status,
-norms, residuals -- the inputs of landscape energy / stuckness) plus the updated candidate
-rows are exchanged with ONE kind of collective: an all-gather (RCCL over xGMI with the
-`nccl` backend; `gloo` in the CPU tests).  The host orchestration is replicated: every rank
-holds the same candidate list and consumes the same RNG streams, so bookkeeping is identical
-on all ranks by construction.  A is replicated (uploaded by each rank).
+The candidate step has no candidate<->candidate data flow: within an iteration every candidate reads
+(A, b, strategy) and its own state (AMS:576).  So the active candidates are block-partitioned over the ranks in list
+order, every rank runs the batched HIP phases for its block only, and the per-candidate scalar records the host
+bookkeeping needs (Rayleigh dots, solve status, norms, residuals -- the inputs of landscape energy / stuckness,
+AMS:424-475) plus the updated candidate rows are exchanged with ONE kind of collective: an all-gather.  The host
+orchestration is replicated: every rank holds the same candidate list and consumes the same RNG streams, so
+bookkeeping is identical on all ranks by construction.  A is replicated (uploaded by each rank); what only one rank
+needs to compute (start-up diagnostics, the Hermitian eigendecomposition) is computed by rank 0 and broadcast.
+
+Two transports behind one interface:
+
+  'rccl'  (GPUs)  the collectives of libmaus_hip itself (csrc/comm.hip: RCCL over xGMI on the context's own stream).
+                  No torch in the process: the ranks are started by any launcher that sets RANK / LOCAL_RANK /
+                  WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run does); the 128-byte RCCL id travels
+                  from rank 0 to the others over a socket on MASTER_ADDR.
+  'gloo'  (CPU)   torch.distributed with the gloo backend: the multi-process tests (tests/test_dist_gloo.py, over the
+                  NumPy device double) and rehearsals of several ranks on one GPU.
 """
 from __future__ import annotations
 
+import contextlib
 import os
+import pickle
+import socket
+import struct
+import time
 
 import numpy as np
 
+_MAGIC = b"MAUSRCCL1"
+
+
+def _token() -> bytes:
+    """What tells this job's id server from anything else that may listen near MASTER_PORT."""
+    return (os.environ.get("TORCHELASTIC_RUN_ID", "") + ":" + os.environ.get("MASTER_PORT", "") + ":" +
+            os.environ.get("WORLD_SIZE", "")).encode()
+
+
+def _exchange_unique_id(rank: int, world: int, make_id, timeout: float = 300.0) -> bytes:
+    """Rank 0 creates the RCCL unique id and serves it to the other ranks of this node over TCP.  The port is the first
+    free one above MASTER_PORT (the launcher's own store listens ON MASTER_PORT); clients probe the same range and check a
+    magic + job token, so a foreign listener is skipped rather than believed."""
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    base = int(os.environ.get("MASTER_PORT", "29500"))
+    ports = [base + 1 + k for k in range(32)]
+    tok = _token()
+    if world == 1:
+        return make_id()
+    if rank == 0:
+        uid = make_id()
+        srv = None
+        for p in ports:
+            try:
+                srv = socket.create_server((addr, p), reuse_port=False)
+                break
+            except OSError:
+                continue
+        if srv is None:
+            raise RuntimeError(f"dist: no free port in {ports[0]}..{ports[-1]} on {addr} for the RCCL id exchange")
+        srv.settimeout(timeout)
+        served = set()
+        deadline = time.time() + timeout
+        try:
+            while len(served) < world - 1:
+                if time.time() > deadline:
+                    raise RuntimeError(f"dist: only {len(served)} of {world - 1} ranks fetched the RCCL id within {timeout:.0f} s")
+                conn, _ = srv.accept()
+                with conn:
+                    conn.settimeout(10.0)
+                    try:
+                        hello = conn.recv(len(_MAGIC) + 8 + 256)
+                        if not hello.startswith(_MAGIC):
+                            continue
+                        r, ln = struct.unpack("<ii", hello[len(_MAGIC):len(_MAGIC) + 8])
+                        if hello[len(_MAGIC) + 8:len(_MAGIC) + 8 + ln] != tok or not (0 < r < world):
+                            continue
+                        conn.sendall(_MAGIC + uid)
+                        served.add(r)
+                    except OSError:
+                        continue
+        finally:
+            srv.close()
+        return uid
+    deadline = time.time() + timeout
+    hello = _MAGIC + struct.pack("<ii", rank, len(tok)) + tok
+    while time.time() < deadline:
+        for p in ports:
+            try:
+                with socket.create_connection((addr, p), timeout=2.0) as s:
+                    s.settimeout(5.0)
+                    s.sendall(hello)
+                    buf = b""
+                    while len(buf) < len(_MAGIC) + 128:
+                        chunk = s.recv(len(_MAGIC) + 128 - len(buf))
+                        if not chunk:
+                            break
+                        buf += chunk
+                    if len(buf) == len(_MAGIC) + 128 and buf.startswith(_MAGIC):
+                        return buf[len(_MAGIC):]
+            except OSError:
+                continue
+        time.sleep(0.2)
+    raise RuntimeError(f"dist: rank {rank} could not fetch the RCCL id from rank 0 on {addr}:{ports[0]}..{ports[-1]}")
+
 
 class PopulationComm:
-    def __init__(self, device_tensors: bool | None = None):
-        import torch
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError("torch.distributed is not initialised")
-        self.torch = torch
-        self.dist = dist
-        self.rank = dist.get_rank()
-        self.world = dist.get_world_size()
-        backend = dist.get_backend()
-        self.on_device = (backend == "nccl") if device_tensors is None else device_tensors
-        self.device = None
-        if self.on_device:
-            self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    """rank / world, the block partition, and the collectives of a sharded run.  `transport`: 'rccl' or 'gloo'."""
+
+    def __init__(self, transport: str | None = None, device_tensors: bool | None = None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+        if transport is None:
+            transport = "gloo" if device_tensors is False else _default_transport()
+        if transport not in ("rccl", "gloo"):
+            raise ValueError(f"PopulationComm: unknown transport {transport!r}")
+        self.transport = transport
+        self.on_device = transport == "rccl"     # candidate rows travel device to device; one rank per GPU is guaranteed
         self.collectives = 0
         self.bytes_gathered = 0
+        self.seconds = 0.0                       # host wall time inside collectives (bench: per-rank report)
+        self.ctx = None
+        self._uid = None
+        if transport == "gloo":
+            import torch
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError("torch.distributed is not initialised (dist.init_from_env('gloo'))")
+            self.torch, self.dist = torch, dist
+            self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        else:
+            from . import _cabi
+            self._uid = _exchange_unique_id(self.rank, self.world, _cabi.comm_unique_id)
+
+    # ---- binding to the device context (rccl: the communicator lives in the library, on the context's stream) ----------
+    def attach(self, ctx) -> None:
+        if self.transport != "rccl" or ctx is self.ctx:
+            return
+        if self.ctx is not None:
+            raise RuntimeError("PopulationComm: already attached to another context (one communicator per context)")
+        ctx.comm_init(self.rank, self.world, self._uid)
+        self.ctx = ctx
+
+    def _need_ctx(self):
+        if self.ctx is None:
+            raise RuntimeError("PopulationComm('rccl') is not attached to a device context yet (DeviceEngine(comm=...) does it)")
+        return self.ctx
 
     # ---- partition -------------------------------------------------------------------------
     def owners(self, n_items: int) -> np.ndarray:
@@ -42,79 +155,127 @@ class PopulationComm:
         sizes = [base + (1 if r < extra else 0) for r in range(self.world)]
         return np.repeat(np.arange(self.world), sizes)
 
-    # ---- collective --------------------------------------------------------------------------
+    # ---- collectives --------------------------------------------------------------------------
+    def _account(self, t0, nbytes):
+        self.collectives += 1
+        self.bytes_gathered += int(nbytes)
+        self.seconds += time.perf_counter() - t0
+
     def allgather_rows(self, local: np.ndarray, counts) -> np.ndarray:
         """local: (counts[rank], width) float64 -> (sum(counts), width), concatenated in rank order."""
-        torch = self.torch
         width = local.shape[1] if local.ndim == 2 else 0
         cmax = int(max(counts)) if len(counts) else 0
         if cmax == 0 or width == 0:
             return np.zeros((int(sum(counts)), width))
+        t0 = time.perf_counter()
         buf = np.zeros((cmax, width), dtype=np.float64)
         buf[: local.shape[0]] = local
-        t = torch.from_numpy(buf)
-        if self.on_device:
-            t = t.to(self.device)
-        out = torch.empty((self.world * cmax, width), dtype=torch.float64, device=t.device)
-        self.dist.all_gather_into_tensor(out, t)
-        self.collectives += 1
-        self.bytes_gathered += out.numel() * 8
-        full = out.cpu().numpy().reshape(self.world, cmax, width)
+        if self.transport == "rccl":
+            full = self._need_ctx().comm_allgather_records(buf, self.world)
+        else:
+            t = self.torch.from_numpy(buf)
+            out = self.torch.empty((self.world * cmax, width), dtype=self.torch.float64)
+            self.dist.all_gather_into_tensor(out, t)
+            full = out.numpy().reshape(self.world, cmax, width)
+        self._account(t0, self.world * cmax * width * 8)
         return np.concatenate([full[r, : counts[r]] for r in range(self.world)], axis=0)
 
-    # ---- candidate rows, device to device ---------------------------------------------------------
-    class _DevArray:
-        """__cuda_array_interface__ view of a population array of the library's context (float64 pairs)."""
-        def __init__(self, ptr, rows, cols):
-            self.__cuda_array_interface__ = {"shape": (rows, cols), "typestr": "<f8", "data": (ptr, False), "version": 2}
-
     def sync_rows_device(self, ctx, which: int, slots_by_rank, length: int) -> None:
-        """After a sharded step every rank holds fresh rows only for its own candidates.  All-gather them over RCCL straight
-        out of / into the contexts' population arrays (one gather kernel, one all-gather, one scatter kernel) -- no host
-        bounce.  slots_by_rank[r] = the slots rank r updated, in list order (identical on every rank)."""
-        torch = self.torch
-        ptr, ld, cap = ctx.pop_device_ptr(which)                 # joins the context's stream
-        X = torch.as_tensor(PopulationComm._DevArray(ptr, cap, 2 * ld), device=self.device)
-        cmax = max((len(s) for s in slots_by_rank), default=0)
-        if cmax == 0:
+        """After a sharded step every rank holds fresh rows only for its own candidates.  slots_by_rank[r] = the slots rank
+        r updated, in list order (identical on every rank): packed, all-gathered over RCCL and scattered straight into the
+        context's population array -- one pack kernel, one all-gather, one unpack kernel, no host bounce."""
+        if self.transport != "rccl":
+            raise RuntimeError("sync_rows_device needs the 'rccl' transport")
+        t0 = time.perf_counter()
+        self._need_ctx().comm_allgather_rows(which, slots_by_rank, length)
+        self._account(t0, sum(len(s) for s in slots_by_rank) * length * 16)
+
+    def bcast_array(self, arr: np.ndarray, root: int = 0) -> np.ndarray:
+        """In-place broadcast of a C-contiguous array that has the same shape and dtype on every rank."""
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes == 0:
+            return arr
+        t0 = time.perf_counter()
+        if self.transport == "rccl":
+            self._need_ctx().comm_bcast(arr, root)
+        else:
+            t = self.torch.from_numpy(arr.view(np.uint8).reshape(-1))
+            self.dist.broadcast(t, src=root)
+        self._account(t0, arr.nbytes)
+        return arr
+
+    def bcast_object(self, obj, root: int = 0):
+        """A picklable object from `root` to every rank (start-up diagnostics)."""
+        payload = pickle.dumps(obj) if self.rank == root else b""
+        ln = self.bcast_array(np.array([len(payload)], dtype=np.int64), root)
+        buf = np.frombuffer(payload, dtype=np.uint8).copy() if self.rank == root else np.empty(int(ln[0]), dtype=np.uint8)
+        self.bcast_array(buf, root)
+        return obj if self.rank == root else pickle.loads(buf.tobytes())
+
+    def bcast_eigvecs(self, ctx, evecs, n: int, root: int = 0) -> None:
+        """The eigenvector matrix of the Hermitian shortcut (AMS:161): decomposed by `root` only, resident on every rank
+        afterwards.  rccl: uploaded once and broadcast device to device; gloo: host broadcast, then each rank uploads."""
+        if self.transport == "rccl":
+            t0 = time.perf_counter()
+            if self.rank == root:
+                ctx.set_eigvecs(evecs)
+            self._need_ctx().comm_bcast_eigvecs(n, root)
+            self._account(t0, 16 * n * n)
             return
-        w = 2 * length
-        send = torch.zeros((cmax, w), dtype=torch.float64, device=self.device)
-        mine = slots_by_rank[self.rank]
-        if len(mine):
-            send[: len(mine)] = X[torch.as_tensor(mine, dtype=torch.long, device=self.device), :w]
-        out = torch.empty((self.world * cmax, w), dtype=torch.float64, device=self.device)
-        self.dist.all_gather_into_tensor(out, send)
-        self.collectives += 1
-        self.bytes_gathered += out.numel() * 8
-        for r, sl in enumerate(slots_by_rank):
-            if len(sl):                                           # own rows too: the same bytes, one code path
-                X[torch.as_tensor(sl, dtype=torch.long, device=self.device), :w] = out[r * cmax: r * cmax + len(sl)]
-        torch.cuda.current_stream(self.device).synchronize()     # the library's stream may read the rows from here on
+        V = np.ascontiguousarray(evecs, dtype=np.complex128) if self.rank == root else np.empty((n, n), dtype=np.complex128)
+        self.bcast_array(V.view(np.float64), root)
+        ctx.set_eigvecs(V)
+
+    def max_over_ranks(self, value: float) -> float:
+        return float(self.allgather_rows(np.array([[float(value)]]), [1] * self.world).max())
 
     def barrier(self):
-        self.dist.barrier()
+        if self.transport == "rccl":
+            self.allgather_rows(np.zeros((1, 1)), [1] * self.world)
+        else:
+            self.dist.barrier()
+
+    def stats(self):
+        return {"collectives": self.collectives, "bytes": self.bytes_gathered, "ms": self.seconds * 1e3}
+
+    @contextlib.contextmanager
+    def all_blas_threads(self):
+        """Work that only ONE rank does while the others wait (start-up diagnostics, the Hermitian eigh) gets the node's
+        cores: launchers such as torch.distributed.run export OMP_NUM_THREADS=1 to every rank, which would run a 73-second
+        decomposition (n = 8192) on one thread."""
+        try:
+            from threadpoolctl import threadpool_limits
+        except Exception:
+            yield
+            return
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except Exception:
+            ncpu = os.cpu_count() or 1
+        with threadpool_limits(limits=max(1, ncpu)):
+            yield
+
+
+def _default_transport() -> str:
+    env = os.environ.get("MAUS_DIST_BACKEND")
+    if env:
+        return {"nccl": "rccl", "rccl": "rccl", "gloo": "gloo"}[env]
+    from . import _cabi
+    return "rccl" if _cabi.device_count() > 0 else "gloo"
 
 
 def init_from_env(backend: str | None = None):
-    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun) if world > 1."""
-    import torch
-    import torch.distributed as dist
+    """The communicator of this process from RANK / WORLD_SIZE / MASTER_* (as set by torch.distributed.run or any other
+    one-process-per-GPU launcher), or None for a single rank.  backend: 'rccl' (alias 'nccl') | 'gloo' | None = rccl when
+    this process sees a GPU, gloo otherwise.  MAUS_FORCE_COMM=1 builds a one-rank communicator (RCCL smoke test)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1 and os.environ.get("MAUS_FORCE_COMM", "0") != "1":     # MAUS_FORCE_COMM=1: a one-rank group (RCCL smoke test)
+    if world <= 1 and os.environ.get("MAUS_FORCE_COMM", "0") != "1":
         return None
-    if not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            # torch's wheel bundles its own HIP runtime under the same soname as /opt/rocm's (libamdhip64.so.7).  Loaded
-            # first, it also serves libmaus_hip.so; loaded second it finds the device already held by the other runtime
-            # ("No HIP GPUs are available", tools/probe_torch_hip_order.py).  So: process group before the first context.
-            if not torch.cuda.is_available():
-                from . import _cabi
-                hint = (" -- libmaus_hip.so was loaded before torch initialised its HIP runtime: call dist.init_from_env() "
-                        "before creating a Context / MAUS_Solver") if _cabi._lib is not None else ""
-                raise RuntimeError("backend 'nccl' needs torch.cuda, which sees no GPU" + hint)
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(backend=backend)
-    return PopulationComm()
+    transport = {"nccl": "rccl", "rccl": "rccl", "gloo": "gloo", None: None}[backend]
+    if transport is None:
+        transport = _default_transport()
+    if transport == "gloo":
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group(backend="gloo")
+    return PopulationComm(transport)

@@ -165,6 +165,8 @@ class DeviceEngine:
             # host-side collectives (gloo): several ranks may be rehearsing on ONE GPU, so kernels whose workgroups wait
             # for each other (multi-workgroup LU panel) must not assume they have the device to themselves
             self.ctx.set_shared_device(True)
+        if comm is not None and hasattr(comm, "attach"):
+            comm.attach(self.ctx)               # 'rccl' transport: the communicator lives in the library, on this context's stream
         self._bound = None                      # matrix object currently on the device
         self._bound_b = None
         self._eig_cache = None                  # (matrix obj, evals) for the Hermitian shortcut
@@ -472,20 +474,56 @@ class DeviceEngine:
         self.ctx.set_eigvecs(evecs)
         self._eig_cache = (A, evals)
 
+    def _eigh_once(self, A):
+        """One decomposition per matrix version instead of one per candidate; the same LAPACK call as the
+        reference (AMS:161), so (lambda, V) are bit-identical to its.  In a sharded run rank 0 alone decomposes -- with
+        the node's BLAS threads, the other ranks are waiting -- and broadcasts the eigenvalues (host) and the
+        eigenvector matrix (device to device over RCCL): N ranks must not run N copies of a 73-second eigh (n = 8192) on
+        one thread each.  Returns (eigenvalues, None) with V resident on the device, or (None, error text)."""
+        import scipy.linalg as sla
+        comm = self.comm
+        n = A.shape[0]
+        if comm is None or comm.world == 1:
+            try:
+                evals, evecs = sla.eigh(A)
+            except np.linalg.LinAlgError as e:
+                return None, str(e)
+            self.ctx.set_eigvecs(evecs)
+            return evals, None
+        evals, evecs, err = np.empty(n, dtype=np.float64), None, ""
+        if comm.rank == 0:
+            try:
+                with comm.all_blas_threads():
+                    ev, evecs = sla.eigh(A)
+                evals[:] = ev
+            except np.linalg.LinAlgError as e:
+                err = str(e) or "eigh failed"
+        err = comm.bcast_object(err)
+        if err:
+            return None, err
+        comm.bcast_array(evals)
+        comm.bcast_eigvecs(self.ctx, evecs, n)
+        return evals, None
+
+    def seed_eigh_distributed(self, A, evals, evecs):
+        """seed_eigh for a sharded run: rank 0 passes the decomposition its start-up diagnostics computed, the other ranks
+        pass None and receive it."""
+        comm = self.comm
+        n = A.shape[0]
+        ev = np.ascontiguousarray(evals, dtype=np.float64) if comm.rank == 0 else np.empty(n, dtype=np.float64)
+        comm.bcast_array(ev)
+        comm.bcast_eigvecs(self.ctx, evecs, n)
+        self._eig_cache = (A, ev)
+
     def _hermitian(self, cands, A):
         from .solver import SolutionCandidate
         S = SolutionCandidate.State
         if self._eig_cache is None or self._eig_cache[0] is not A:
-            import scipy.linalg as sla
-            try:
-                # one decomposition per matrix version instead of one per candidate;
-                # same LAPACK call as the reference so (lambda, V) are bit-identical to its
-                evals, evecs = sla.eigh(A)
-            except np.linalg.LinAlgError as e:
+            evals, err = self._eigh_once(A)
+            if evals is None:
                 for c in cands:
-                    print(f"Candidate {c.id}: Dense Hermitian solver (eigh) failed: {e}. Falling back.")
+                    print(f"Candidate {c.id}: Dense Hermitian solver (eigh) failed: {err}. Falling back.")
                 return cands
-            self.ctx.set_eigvecs(evecs)
             self._eig_cache = (A, evals)
         evals = self._eig_cache[1]
         idx, _ = self.d_herm_match(cands)

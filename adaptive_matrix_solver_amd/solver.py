@@ -426,17 +426,30 @@ class MAUS_Solver:
         # seam) keeps the reference's exact computation
         self._cond_device = device if (engine is None and cond_exact_max is not None) else None
         self._cond_exact_max = cond_exact_max
+        # `engine` is a test seam (tests/fake_ctx.py drives the host logic without a GPU); product
+        # code never passes it, and DeviceEngine() raises if libmaus_hip / the device is missing
+        self.engine = engine if engine is not None else DeviceEngine(device=device, pert_mode=pert_mode,
+                                                                     gmres_compat=gmres_compat, comm=comm)
         # `diag_info`: start-up diagnostics of the same matrix taken from an earlier solver (bench side runs)
-        self.diag_info = dict(diag_info) if diag_info is not None else self._diagnose_matrix_initial(self.M)
-        if comm is not None and diag_info is None:
-            # every rank diagnosed the matrix on its own GPU; rank 0's numbers are authoritative so that the strategy --
-            # and with it the sequence of collectives -- cannot diverge between ranks
-            rec = np.array([[float(self.diag_info["condition_number"]), float(self.diag_info["is_singular"]),
-                             float(self.diag_info.get("condition_number_is_estimate", False))]])
-            allr = comm.allgather_rows(rec, [1] * comm.world)
-            self.diag_info["condition_number"] = float(allr[0, 0])
-            self.diag_info["is_singular"] = bool(allr[0, 1])
-            self.diag_info["condition_number_is_estimate"] = bool(allr[0, 2])
+        if diag_info is not None:
+            self.diag_info = dict(diag_info)
+        elif comm is None or comm.world == 1:
+            self.diag_info = self._diagnose_matrix_initial(self.M)
+        else:
+            # Sharded run: rank 0 alone diagnoses the matrix (AMS:374-404: symmetry checks, condition number -- an SVD or,
+            # for a Hermitian eigenproblem, the eigh the shortcut needs anyway) with the node's BLAS threads, and broadcasts
+            # the result: N ranks must not repeat an O(n^3) host computation, and the strategy -- with it the sequence of
+            # collectives -- cannot diverge between ranks.
+            di = None
+            if comm.rank == 0:
+                with comm.all_blas_threads():
+                    di = self._diagnose_matrix_initial(self.M)
+                di["_eigh_seed"] = "_eigh_seed" in self.__dict__
+            self.diag_info = comm.bcast_object(di)
+            if self.diag_info.pop("_eigh_seed", False):
+                self.engine.bind_matrix(self.M)
+                seed = self.__dict__.pop("_eigh_seed", None)
+                self.engine.seed_eigh_distributed(self.M, *(seed[1:] if seed is not None else (None, None)))
         self.is_sparse_problem_init = self.diag_info["is_sparse_init"]
         self.cond_number = self.diag_info["condition_number"]
         self.problem_knowledge = {
@@ -455,10 +468,6 @@ class MAUS_Solver:
             "convergence_tolerance": global_convergence_tol, "current_convergence_threshold": global_convergence_tol,
         }
         self._set_initial_strategy()
-        # `engine` is a test seam (tests/fake_ctx.py drives the host logic without a GPU); product
-        # code never passes it, and DeviceEngine() raises if libmaus_hip / the device is missing
-        self.engine = engine if engine is not None else DeviceEngine(device=device, pert_mode=pert_mode,
-                                                                     gmres_compat=gmres_compat, comm=comm)
         self.engine.bind_matrix(self.M)
         seed = self.__dict__.pop("_eigh_seed", None)
         if seed is not None:

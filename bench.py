@@ -123,8 +123,9 @@ def main():
                          "single-matrix LUs would otherwise be mixed into rocprofv3's per-kernel averages; the timed loop "
                          "bodies are the same")
     ap.add_argument("--launch-check", action="store_true",
-                    help="start the ranks, form the process group, all-gather the rank ids, print {n_gpus} and exit "
-                         "without touching a GPU (tests/test_dist_gloo.py checks the --gpus N self-launch with it)")
+                    help="start the ranks, form the communicator, all-gather the rank ids, print {n_gpus} and exit "
+                         "(with MAUS_DIST_BACKEND=gloo without touching a GPU: tests/test_dist_gloo.py checks the --gpus N "
+                         "self-launch with it)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -138,12 +139,17 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; start one rank per GPU "
                  f"(python bench.py --gpus N does that itself)")
     comm = None
-    backend = os.environ.get("MAUS_DIST_BACKEND", "nccl")
+    # 'rccl' (alias 'nccl'): the library's own RCCL collectives, one rank per GPU, no torch in the process;
+    # MAUS_DIST_BACKEND=gloo lets several ranks share one GPU (or none: --launch-check) for rehearsal
+    backend = {"nccl": "rccl"}.get(os.environ.get("MAUS_DIST_BACKEND", "rccl"), os.environ.get("MAUS_DIST_BACKEND", "rccl"))
     if args.launch_check:
         ranks = [0]
         if world > 1:
             from adaptive_matrix_solver_amd import dist as mdist
             comm = mdist.init_from_env(backend)
+            if comm.transport == "rccl":          # the communicator lives on a device context (one per GPU)
+                from adaptive_matrix_solver_amd import Context
+                comm.attach(Context(local_rank))
             ranks = comm.allgather_rows(np.array([[float(rank)]]), [1] * world)[:, 0].astype(int).tolist()
             comm.barrier()
         if rank == 0:
@@ -151,7 +157,6 @@ def main():
         return
     if world > 1:
         from adaptive_matrix_solver_amd import dist as mdist
-        # nccl == RCCL over xGMI; MAUS_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsal
         comm = mdist.init_from_env(backend)
 
     import scenarios
@@ -159,7 +164,7 @@ def main():
 
     n, P = args.n, args.pop
     A = scenarios.ginibre(n, n)                 # (G1 + i G2)/sqrt(n), seed n  
-    device = local_rank if backend == "nccl" else 0
+    device = local_rank if backend == "rccl" else 0
 
     def build(pop, engine=None, diag=None):
         np.random.seed(1234); random.seed(1234); SolutionCandidate._candidate_id_counter = 0
@@ -178,11 +183,8 @@ def main():
     info = ctx.device_info()
 
     def sync_all():
-        ctx.sync()
+        ctx.sync()                               # every kernel and collective of this rank runs on the context's stream
         if comm is not None:
-            if comm.on_device:
-                import torch
-                torch.cuda.synchronize()
             comm.barrier()
 
     it = 0
@@ -208,6 +210,7 @@ def main():
     ctx.shifted_lu_solve = _timed_lu
     ctx.profile_enable(mode)
     sync_all()
+    comm0 = comm.stats() if comm is not None else None
     t0 = time.perf_counter()
     steps_done = 0
     per_step = []
@@ -216,10 +219,15 @@ def main():
         it += 1
         ts = time.perf_counter()
         lu_wall[0] = 0.0
+        c_before = comm.stats() if comm is not None else None
         act = solver.loop_body(it)               # ends synchronously: the host fetched every phase's results
         te = time.perf_counter()
         steps_done += act
         rec = {"ms": round((te - ts) * 1e3, 3), "active": act, "lu_call_ms": round(lu_wall[0] * 1e3, 3)}
+        if comm is not None:
+            c_after = comm.stats()
+            rec["collective_ms"] = round(c_after["ms"] - c_before["ms"], 3)
+            rec["collectives"] = c_after["collectives"] - c_before["collectives"]
         if mode:
             z = ctx.profile_read_class(0)        # cumulative since profile_enable
             rec["k256_union_ms"] = round(z["union_ms"] - cum_union, 3)
@@ -228,11 +236,22 @@ def main():
         per_step.append(rec)
     sync_all()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if comm is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=comm.device if comm.on_device else "cpu")
-        comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # max over ranks of the timed region; and every rank's own view of it (loop-body wall times, time inside
+        # maus_shifted_lu_solve, time inside collectives) gathered to rank 0 for the JSON line
+        c1 = comm.stats()
+        mine = np.array([[elapsed, (c1["ms"] - comm0["ms"]) * 1e-3, float(c1["collectives"] - comm0["collectives"]),
+                          float(c1["bytes"] - comm0["bytes"])] +
+                         [r["ms"] for r in per_step] + [r["lu_call_ms"] for r in per_step] + [r["collective_ms"] for r in per_step]])
+        allr = comm.allgather_rows(mine, [1] * world)
+        elapsed = float(allr[:, 0].max())
+        K = args.steps
+        per_rank = [{"rank": r, "elapsed_s": round(float(allr[r, 0]), 4), "collective_s": round(float(allr[r, 1]), 4),
+                     "collectives": int(allr[r, 2]), "collective_bytes": int(allr[r, 3]),
+                     "loop_body_ms": [round(float(x), 2) for x in allr[r, 4:4 + K]],
+                     "lu_call_ms": [round(float(x), 2) for x in allr[r, 4 + K:4 + 2 * K]],
+                     "collective_ms": [round(float(x), 3) for x in allr[r, 4 + 2 * K:4 + 3 * K]]} for r in range(world)]
     prof = ctx.profile_read()
     ctx.profile_enable(False)
     ws_allocs = ctx.lu_workspace_allocations()
@@ -340,6 +359,7 @@ def main():
                                      "device from the NumPy state)") if n > 256 else "uniform (host draws uploaded)",
                        "device": info["name"], "solver_build_s": round(t_build, 2)},
             "per_step": per_step,
+            "per_rank": per_rank,
             "per_step_summary": {"ms_per_candidate_step_median": round(float(np.median(ms_norm)), 4),
                                  "ms_per_candidate_step_max": round(float(np.max(ms_norm)), 4),
                                  "lu_workspace_allocations_total": ws_allocs,

@@ -23,9 +23,17 @@ def _free_port():
     return p
 
 
+# populations smaller than the world size: in every step some ranks own no candidate at all
+EXTRA = {"eig16_p5": dict(kind="eig", build=("ginibre", 16, 16, 1.0), P=5, iters=4, seed=1234, tol=1e-8),
+         "svd3x2_p3": dict(kind="svd", build=("svd", 3, 2, 21, -3.0), P=3, iters=4, seed=11, tol=1e-6),
+         "herm16_p3": dict(kind="eig", build=("hermitian", 16, 16), P=3, iters=3, seed=5, tol=1e-8)}
+
+
 def _run(name, iters, comm):
     sys.path[:0] = [ROOT, os.path.join(HERE, "golden"), HERE]
+    import scenarios
     import snapshot
+    scenarios.TRAJECTORIES.update(EXTRA)
     from test_host_logic import make_solver, rows_of
     solver, spec = make_solver(name, comm=comm)
     out = []
@@ -42,26 +50,57 @@ def _worker(rank, world, port, name, iters, outdir):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path[:0] = [ROOT]
+    import scipy.linalg as sla
     from adaptive_matrix_solver_amd.dist import PopulationComm
-    comm = PopulationComm()
+    comm = PopulationComm("gloo")
+    # what the sharding did: sizes of the partitions asked for, and who called the O(n^3) host routines
+    asked, eigh_calls = [], [0]
+    owners = comm.owners
+    comm.owners = lambda n: (asked.append(int(n)), owners(n))[1]
+    real_eigh = sla.eigh
+    sla.eigh = lambda *a, **k: (eigh_calls.__setitem__(0, eigh_calls[0] + 1), real_eigh(*a, **k))[1]
     out, ncoll = _run(name, iters, comm)
     with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
-        json.dump({"out": out, "collectives": ncoll}, f)
+        json.dump({"out": out, "collectives": ncoll, "asked": asked, "eigh_calls": eigh_calls[0],
+                   "stats": comm.stats()}, f)
     dist.barrier()
     dist.destroy_process_group()
 
 
+def _spawn(world, name, iters):
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), name, iters, d), nprocs=world, join=True)
+        return [json.load(open(os.path.join(d, f"rank{r}.json"))) for r in range(world)]
+
+
 @pytest.mark.parametrize("name,iters", [("eig16", 6), ("lap8", 12), ("svd5x4", 8), ("lin24", 6), ("herm16", 3)])
 def test_two_ranks_equal_single_process(name, iters):
-    import torch.multiprocessing as mp
     ref, _ = _run(name, iters, None)
-    with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, _free_port(), name, iters, d), nprocs=2, join=True)
-        got = [json.load(open(os.path.join(d, f"rank{r}.json"))) for r in range(2)]
+    got = _spawn(2, name, iters)
     for r in range(2):
         assert got[r]["out"] == ref, f"rank {r} diverged from the single-process run"
         assert got[r]["collectives"] > 0
     assert got[0]["collectives"] == got[1]["collectives"]
+
+
+# world sizes that do not divide the population, and more ranks than active candidates: lin24 steps 10 -> 1 candidates,
+# svd5x4 25 -> 13, herm16 12 (Hermitian shortcut: rank 0 alone decomposes the matrix and broadcasts lambda and V)
+@pytest.mark.parametrize("world,name,iters", [(3, "eig16", 5), (3, "herm16", 3), (8, "lin24", 6), (8, "eig16_p5", 4), (8, "svd3x2_p3", 4),
+                                              (8, "herm16_p3", 3)])
+def test_three_and_eight_ranks_equal_single_process(world, name, iters):
+    ref, _ = _run(name, iters, None)
+    got = _spawn(world, name, iters)
+    for r in range(world):
+        assert got[r]["out"] == ref, f"rank {r} of {world} diverged from the single-process run"
+        assert got[r]["collectives"] == got[0]["collectives"] > 0
+        assert got[r]["asked"] == got[0]["asked"]
+    steps = [n for n in got[0]["asked"] if n > 0]
+    if name in EXTRA:
+        assert min(steps) < world, "no step in which some ranks owned no candidate"
+    if name.startswith("herm16"):
+        # one eigh per matrix, on rank 0 only (the reference: one per candidate step, AMS:161)
+        assert [g["eigh_calls"] for g in got] == [1] + [0] * (world - 1)
 
 
 def test_owner_partition_is_contiguous_and_balanced():
@@ -98,6 +137,10 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     assert len(line) == 1, r.stdout                                   # ONE JSON line, from rank 0
     rec = json.loads(line[0])
     assert rec == {"launch_check": True, "n_gpus": 2, "ranks": [0, 1], "backend": "gloo"}
+    r8 = _bench(["--gpus", "8", "--launch-check"], {"MAUS_DIST_BACKEND": "gloo"})
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    rec8 = json.loads([l for l in r8.stdout.splitlines() if l.startswith("{")][0])
+    assert rec8["n_gpus"] == 8 and rec8["ranks"] == list(range(8))
     # a single rank needs no launcher
     r1 = _bench(["--gpus", "1", "--launch-check"])
     assert r1.returncode == 0 and json.loads(r1.stdout.strip())["n_gpus"] == 1
