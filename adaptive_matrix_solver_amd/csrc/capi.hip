@@ -383,7 +383,7 @@ int maus_matvec_rayleigh(maus_ctx* c, const int* slots, int count, double* num, 
 static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     int npad = round_up(n, 32);
     if (npad > maus_lu_max_npad()) FAIL(c, "direct LU path supports n <= 8192 in this build");
-    size_t per = 2 * sizeof(c128) * (size_t)npad * (npad + 32);    // H and the logical-order U array (implicit pivoting)
+    size_t per = 2 * sizeof(c128) * (size_t)npad * lu_ntiles(npad) * LU_TW;    // H and the logical-order U array (implicit pivoting), tile-major (luws.h)
     if (c->H && c->Hnpad == npad && (c->Hg >= want || c->ws_at_limit)) return 0;     // at the limit: callers chunk
     const bool second = c->H && c->Hnpad == npad;
     size_t fr = 0, tot = 0;
@@ -436,7 +436,7 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
 
 static LuWs make_ws(maus_ctx* c, int n, int G) {
     LuWs w;
-    w.n = n; w.npad = c->Hnpad; w.ldh = w.npad + 32; w.strideH = (long)w.npad * w.ldh; w.G = G;
+    w.n = n; w.npad = c->Hnpad; w.ldh = w.npad + 32; w.strideH = (long)w.npad * lu_ntiles(w.npad) * LU_TW; w.G = G;
     w.H = c->H; w.U = c->H + (size_t)c->Hg * w.strideH; w.perm = c->perm; w.ipiv = c->ipiv; w.info = c->info; w.flags = c->flags; w.st = c->st;
     w.tick = prof_tick; w.ud = c;
     return w;
@@ -493,7 +493,7 @@ static void mw_configure(const maus_ctx* c, LuWs& w) {
 // draw index m, then over the sub-stream index b), then the H build that regenerates the draws (mtdev.hip).  The plan
 // itself (pure host arithmetic on stream offsets) lives in mtplan.cpp so that it can be built and run under the CPU
 // sanitizers (`make asan`).
-static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* d, int first, int g, int rhs_mode, int lo, int sbi) {
+static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* d, int first, int g, int rhs_mode, int lo, int sbi, int tiled) {
     if ((int)c->mt_bufs.size() <= sbi) c->mt_bufs.resize(sbi + 1);
     maus_ctx::MtBuf& mb = c->mt_bufs[sbi];
     const int n = w.n;
@@ -543,7 +543,7 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
     const int* d_extra = mb.ints; const int* d_rpos = mb.ints + ngen;
     prof_tick(c, KC_BUILD, 0, 0, 0);
     maus_build_h_mt(w.st, c->A, n, w.npad, w.ldh, w.strideH, w.H, g, pl.S, (long)pl.E, c->d_c1 + lo, c->d_r1 + lo, rhs_mode, c->X, c->ldp,
-                    c->d_slots + lo, c->b, mb.states, d_extra, d_rpos, w.flags);
+                    c->d_slots + lo, c->b, mb.states, d_extra, d_rpos, w.flags, tiled);
     prof_tick(c, KC_BUILD, 1, 0, 32.0 * w.npad * w.ldh * g);
     return 0;
 }
@@ -630,10 +630,10 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             if (S == 1) mw_configure(c, w);              // the only LU in flight on this device: the panel may spread over several workgroups per matrix
             c->prof_st = st;
             if (pert_mode == MAUS_PERT_MT19937) {
-                if (mt_prepare_and_build(c, w, (const maus_mt_desc*)pert_data, off + lo, g, rhs_mode, lo, sb)) return -1;
+                if (mt_prepare_and_build(c, w, (const maus_mt_desc*)pert_data, off + lo, g, rhs_mode, lo, sb, 1)) return -1;
             } else
             maus_build_h(w, c->A, c->d_c1 + lo, c->d_r1 + lo, rhs_mode, c->X, c->ldp, c->d_slots + lo, c->b, pert_mode,
-                         dU ? dU + 2 * (size_t)n * n * lo : nullptr);
+                         dU ? dU + 2 * (size_t)n * n * lo : nullptr, 1);
             wss.push_back(w); los.push_back(lo);
         }
         // (A token schedule that lets only one sub-batch at a time into its panel phase -- so that it always runs
@@ -864,9 +864,9 @@ int maus_gmres_pert(maus_ctx* c, const int* slots, int count, const double* shif
             dU = c->Upert;
         }
         if (pert_mode == MAUS_PERT_MT19937) {
-            if (mt_prepare_and_build(c, w, (const maus_mt_desc*)pert_data, off, G, rhs_mode, 0, 0)) return -1;
+            if (mt_prepare_and_build(c, w, (const maus_mt_desc*)pert_data, off, G, rhs_mode, 0, 0, 0)) return -1;
         } else
-            maus_build_h(w, c->A, c->d_c1, c->d_r1, rhs_mode, c->X, c->ldp, c->d_slots, c->b, pert_mode, dU);
+            maus_build_h(w, c->A, c->d_c1, c->d_r1, rhs_mode, c->X, c->ldp, c->d_slots, c->b, pert_mode, dU, 0);     // row-major: one dense GEMV operand per candidate
         HIPCHK(c, hipMemcpyAsync(h_flags.data(), c->flags, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
         if (maus_gmres_run(c, slots + off, G, shift + 2 * (size_t)off, psi + off, rhs_mode, want_jacobi + off, rtol, restart, maxiter,
                            info_out + off, inner_out + off, status + off, w.H, w.ldh, w.strideH, jacobi_out ? jacobi_out + off : nullptr))

@@ -13,7 +13,7 @@
 void maus_lu_factor(const LuWs& w, int nbo);
 void maus_lu_backsolve(const LuWs& w, c128* Wpop, long ldw, const int* d_slots, c128* xout_dense);
 void maus_build_h(const LuWs& w, const c128* A, const c128* d_shift, const double* d_psi, int rhs_mode,
-                  const c128* X, long ldx, const int* d_slots, const c128* bvec, int pert_mode, const double* d_U);
+                  const c128* X, long ldx, const int* d_slots, const c128* bvec, int pert_mode, const double* d_U, int tiled);
 void maus_load_h(const LuWs& w, const c128* d_Ain, const c128* d_bin);
 int maus_lu_max_npad();
 size_t maus_lu_mw_sync_bytes();
@@ -22,7 +22,7 @@ void maus_mt_jump(hipStream_t st, uint32_t* states, const int* sel, int nsel, co
 int maus_mt_zero_tap();
 void maus_build_h_mt(hipStream_t st, const c128* A, int n, int npad, long ldh, long strideH, c128* H, int G, int S, long E,
                      const c128* d_shift, const double* d_psi, int rhs_mode, const c128* X, long ldx, const int* d_slots,
-                     const c128* bvec, const uint32_t* states, const int* extra, const int* rpos, int* flags);
+                     const c128* bvec, const uint32_t* states, const int* extra, const int* rpos, int* flags, int tiled);
 int maus_mt_jump_poly(uint64_t J, uint64_t* out312);
 void maus_zgemm_launch_idx(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,
                            const c128* B, long ldb, long sB, c128* C, long ldc, long sC,

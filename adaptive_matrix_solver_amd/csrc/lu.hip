@@ -31,6 +31,9 @@ void maus_zgemm_launch(hipStream_t st, int M, int N, int K, const c128* A, long 
                        const c128* B, long ldb, long sB, c128* C, long ldc, long sC,
                        double alpha, int beta, int batch, int blay, bool conja, bool conjb);
 
+void maus_zgemm_launch_lu(hipStream_t st, int M, int N, int K, const c128* H, const c128* U, c128* Hc, long nrows, long stride,
+                          int acol, int brow, int ccol, int batch, const int* rows, long rows_stride);
+
 void maus_zgemm_launch_rows(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,
                             const c128* B, long ldb, long sB, c128* C, long ldc, long sC,
                             double alpha, int beta, int batch, int blay, bool conja, bool conjb,
@@ -59,10 +62,12 @@ build_h_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long strid
                int rhs_mode, const c128* __restrict__ X, long ldx, const int* __restrict__ slots,
                const c128* __restrict__ bvec,
                int pert_mode, const double* __restrict__ U /* [G][2][n][n] */,
-               int* __restrict__ flags)
+               int* __restrict__ flags, int tiled)
 {
     const int i = blockIdx.x, g = blockIdx.y;
-    c128* Hrow = Hg + (long)g * strideH + (long)i * ldh;
+    // element (i, j): row-major with leading dimension ldh (GMRES operand) or tile-major (LU workspace, luws.h)
+    c128* Hmat = Hg + (long)g * strideH;
+    auto at = [&](int j) -> c128& { return Hmat[tiled ? lu_tix(npad, i, j) : (long)i * ldh + j]; };
     const c128 lam = shift[g];
     const double ps = psi[g];
     bool bad = false;
@@ -86,11 +91,11 @@ build_h_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long strid
                 h.y = __dadd_rn(a.y, pi);
             }
             bad |= !cfinite(h);
-            Hrow[j] = h;
+            at(j) = h;
         }
-        for (int j = n + threadIdx.x; j < npad; j += blockDim.x) Hrow[j] = cmake(0.0, 0.0);
+        for (int j = n + threadIdx.x; j < npad; j += blockDim.x) at(j) = cmake(0.0, 0.0);
     } else {
-        for (int j = threadIdx.x; j < npad; j += blockDim.x) Hrow[j] = cmake(j == i ? 1.0 : 0.0, 0.0);
+        for (int j = threadIdx.x; j < npad; j += blockDim.x) at(j) = cmake(j == i ? 1.0 : 0.0, 0.0);
     }
     // augmented block: column npad = rhs, the other 31 columns zero
     for (int j = threadIdx.x; j < AUG; j += blockDim.x) {
@@ -99,7 +104,7 @@ build_h_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long strid
             v = (rhs_mode == 0) ? X[(long)slots[g] * ldx + i] : bvec[i];
             bad |= !cfinite(v);
         }
-        Hrow[npad + j] = v;
+        at(npad + j) = v;
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[g], 1);
 }
@@ -110,17 +115,18 @@ load_h_kernel(const c128* __restrict__ Ain /*[G][n][n]*/, const c128* __restrict
               long ldh, long strideH, c128* __restrict__ Hg, int* __restrict__ flags)
 {
     const int i = blockIdx.x, g = blockIdx.y;
-    c128* Hrow = Hg + (long)g * strideH + (long)i * ldh;
+    c128* Hmat = Hg + (long)g * strideH;                         // tile-major (luws.h)
+    (void)ldh;
     bool bad = false;
     for (int j = threadIdx.x; j < npad; j += blockDim.x) {
         c128 v = cmake((i == j && i >= n) ? 1.0 : 0.0, 0.0);
         if (i < n && j < n) { v = Ain[((long)g * n + i) * n + j]; bad |= !cfinite(v); }
-        Hrow[j] = v;
+        Hmat[lu_tix(npad, i, j)] = v;
     }
     for (int j = threadIdx.x; j < AUG; j += blockDim.x) {
         c128 v = cmake(0.0, 0.0);
         if (j == 0 && i < n) { v = bin[(long)g * n + i]; bad |= !cfinite(v); }
-        Hrow[npad + j] = v;
+        Hmat[lu_tix(npad, i, npad + j)] = v;
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[g], 1);
 }
@@ -178,8 +184,9 @@ __global__ void __launch_bounds__(PT)
 lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long strideH, int j0, int m,
                    int* __restrict__ ipiv_g, int* __restrict__ perm_g, int npad, int* __restrict__ info_g)
 {
-    c128* Hm = Hg + (long)blockIdx.x * strideH + j0;                       // physical row 0, panel column 0
-    c128* Um = Ug + (long)blockIdx.x * strideH + (long)j0 * ld + j0;       // logical row j0, panel column 0
+    // tile-major workspace: the 16 panel columns lie inside one 64-column tile, where rows are `ld` = 64 elements apart
+    c128* Hm = Hg + (long)blockIdx.x * strideH + lu_tile_off(npad, j0);                    // physical row 0, panel column 0
+    c128* Um = Ug + (long)blockIdx.x * strideH + lu_tile_off(npad, j0) + (long)j0 * ld;    // logical row j0, panel column 0
     int* ipiv = ipiv_g + (long)blockIdx.x * npad + j0;
     int* perm = perm_g + (long)blockIdx.x * npad + j0;                     // perm[r]: physical row of panel-local logical row r
 
@@ -393,8 +400,8 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
     // blockIdx.x = matrix, blockIdx.y = row chunk: workgroups are dealt round-robin over the 8 XCDs by linear id, so with a
     // batch that is a multiple of 8 the W workgroups of one matrix share an XCD -- and its L2 -- (speed only)
     const int w = blockIdx.y, g = blockIdx.x;
-    c128* Hm = Hg + (long)g * strideH + j0;
-    c128* Um = Ug + (long)g * strideH + (long)j0 * ld + j0;
+    c128* Hm = Hg + (long)g * strideH + lu_tile_off(npad, j0);                             // tile-major: see lu_panel_ip_kernel
+    c128* Um = Ug + (long)g * strideH + lu_tile_off(npad, j0) + (long)j0 * ld;
     int* ipiv = ipiv_g + (long)g * npad + j0;
     int* perm = perm_g + (long)g * npad + j0;                     // perm[r]: physical row of panel-local logical row r
     MwSync* sy = sync_g + g;
@@ -610,26 +617,27 @@ trsm_ip_kernel(const c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long
 {
     __shared__ c128 sL[TW][TW + 1];
     __shared__ int sp[TW];
-    const c128* H = Hg + (long)blockIdx.y * strideH;
+    const c128* H = Hg + (long)blockIdx.y * strideH;              // tile-major (luws.h); ld = 64 = row step inside a tile
     c128* U = Ug + (long)blockIdx.y * strideH;
     if (threadIdx.x < TW) sp[threadIdx.x] = perm_g[(long)blockIdx.y * npad + j + threadIdx.x];
     __syncthreads();
     for (int e = threadIdx.x; e < TW * TW; e += blockDim.x) {
-        int r = e / TW, c = e % TW;
-        sL[r][c] = H[(long)sp[r] * ld + j + c];
+        int r = e / TW, c = e % TW;                                // (j is a multiple of 16 only: a 32-wide block may straddle two tiles)
+        sL[r][c] = H[lu_tile_off(npad, j + c) + (long)sp[r] * ld];
     }
     __syncthreads();
     const int col = c_lo + blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= c_hi) return;
+    const long tc = lu_tile_off(npad, col);
     c128 x[TW];
 #pragma unroll
-    for (int i = 0; i < TW; ++i) x[i] = H[(long)sp[i] * ld + col];
+    for (int i = 0; i < TW; ++i) x[i] = H[tc + (long)sp[i] * ld];
 #pragma unroll
     for (int i = 1; i < TW; ++i)
 #pragma unroll
         for (int q = 0; q < i; ++q) cfms(x[i], sL[i][q], x[q]);
 #pragma unroll
-    for (int i = 0; i < TW; ++i) U[(long)(j + i) * ld + col] = x[i];
+    for (int i = 0; i < TW; ++i) U[tc + (long)(j + i) * ld] = x[i];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -654,19 +662,19 @@ backsolve_kernel(const c128* __restrict__ Hg, long ld, long strideH, int n, int 
         // rhs_i = y_i - U[i, jt:] . x[jt:]  ; 16 waves x 2 rows
         for (int rr = 0; rr < BSB / 16; ++rr) {
             const int i = i0 + wave * (BSB / 16) + rr;
-            const c128* row = H + (long)i * ld;
+            const c128* row = H + (long)i * ld;                    // tile-major (luws.h): + tile offset of the column
             double sr = 0.0, si = 0.0;
             for (int j = jt + lane; j < npad; j += 64) {
-                const c128 u = row[j], xv = sx[j];
+                const c128 u = row[lu_tile_off(npad, j)], xv = sx[j];
                 sr = fma(u.x, xv.x, sr); sr = fma(-u.y, xv.y, sr);
                 si = fma(u.x, xv.y, si); si = fma(u.y, xv.x, si);
             }
             sr = wave_sum(sr); si = wave_sum(si);
-            if (lane == 0) { const c128 y = row[npad]; sR[i - i0] = cmake(y.x - sr, y.y - si); }
+            if (lane == 0) { const c128 y = row[lu_tile_off(npad, npad)]; sR[i - i0] = cmake(y.x - sr, y.y - si); }
         }
         for (int e = tid; e < BSB * BSB; e += blockDim.x) {
             int r = e / BSB, c = e % BSB;
-            sD[r * (BSB + 1) + c] = H[(long)(i0 + r) * ld + i0 + c];
+            sD[r * (BSB + 1) + c] = H[lu_tile_off(npad, i0 + c) + (long)(i0 + r) * ld];
         }
         __syncthreads();
         if (wave == 0) {
@@ -704,9 +712,7 @@ static void lu_gemm(const LuWs& w, int r0, int r1, int c0, int c1, int k0, int k
     static FILE* trace = [] { const char* e = getenv("MAUS_LU_TRACE"); return e ? fopen(e, "a") : (FILE*)nullptr; }();
     if (trace) { fprintf(trace, "%d %d %d %d\n", M, N, K, w.G); fflush(trace); }
     prof(w, kc, 0);
-    maus_zgemm_launch_rows(w.st, M, N, K, w.H + k0, w.ldh, w.strideH,
-                           w.U + (long)k0 * w.ldh + c0, w.ldh, w.strideH,
-                           w.H + c0, w.ldh, w.strideH, -1.0, 1, w.G, 0, false, false, w.perm + r0, w.perm + r0, w.npad);
+    maus_zgemm_launch_lu(w.st, M, N, K, w.H, w.U, w.H, w.npad, w.strideH, k0, k0, c0, w.G, w.perm + r0, w.npad);
     prof(w, kc, 1, 8.0 * M * N * K * w.G, 16.0 * ((double)M * K + (double)K * N + 2.0 * M * N) * w.G);
 }
 
@@ -722,11 +728,11 @@ static void lu_trsm(const LuWs& w, int j, int k, int c_lo, int c_hi) {
         const bool thin = (long)grid.x * w.G < 1024;
         dim3 g64((c_hi - c_lo + 63) / 64, w.G);
         if (k == 32 && NBP < 32) {
-            if (thin) hipLaunchKernelGGL((trsm_ip_kernel<32, 64>), g64, dim3(64), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
-            else hipLaunchKernelGGL((trsm_ip_kernel<32>), grid, dim3(256), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+            if (thin) hipLaunchKernelGGL((trsm_ip_kernel<32, 64>), g64, dim3(64), 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+            else hipLaunchKernelGGL((trsm_ip_kernel<32>), grid, dim3(256), 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
         } else {
-            if (thin) hipLaunchKernelGGL((trsm_ip_kernel<NBP, 64>), g64, dim3(64), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
-            else hipLaunchKernelGGL((trsm_ip_kernel<NBP>), grid, dim3(256), 0, w.st, w.H, w.U, w.ldh, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+            if (thin) hipLaunchKernelGGL((trsm_ip_kernel<NBP, 64>), g64, dim3(64), 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+            else hipLaunchKernelGGL((trsm_ip_kernel<NBP>), grid, dim3(256), 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
         }
         prof(w, KC_TRSM, 1, 4.0 * k * k * (c_hi - c_lo) * w.G, 32.0 * k * (c_hi - c_lo) * w.G);
         return;
@@ -742,7 +748,7 @@ static void lu_panel(const LuWs& w, int j0) {
     prof(w, KC_PANEL, 0);
     dim3 grid(w.G), block(PT);
     int rpt = (m + PT - 1) / PT;
-#define PANEL_IP(R, W) hipLaunchKernelGGL((lu_panel_ip_kernel<R, W>), grid, block, 0, w.st, w.H, w.U, w.ldh, w.strideH, j0, m, w.ipiv, w.perm, w.npad, w.info)
+#define PANEL_IP(R, W) hipLaunchKernelGGL((lu_panel_ip_kernel<R, W>), grid, block, 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, j0, m, w.ipiv, w.perm, w.npad, w.info)
     // Small batches: several workgroups per matrix (lu_panel_mw_kernel).  Only when the caller guarantees that this is the
     // only LU in flight on the device (w.mw_sync set) and all G*W workgroups fit on the chip at once -- the workgroups of a
     // matrix wait for each other.
@@ -758,14 +764,18 @@ static void lu_panel(const LuWs& w, int j0) {
         if (W >= 2 && W <= wmax) {
             (void)hipMemsetAsync(w.mw_sync, 0, sizeof(MwSync) * (size_t)w.G, w.st);
             const int rpt1 = (m + W * PT - 1) / (W * PT);
-            if (rpt1 <= 1) hipLaunchKernelGGL((lu_panel_mw_kernel<1>), dim3(w.G, W), block, 0, w.st, w.H, w.U, w.ldh, w.strideH, j0, m, W, w.ipiv, w.perm, w.npad, w.info, (MwSync*)w.mw_sync, w.mw_timeout, w.mw_force_abort);
-            else hipLaunchKernelGGL((lu_panel_mw_kernel<2>), dim3(w.G, W), block, 0, w.st, w.H, w.U, w.ldh, w.strideH, j0, m, W, w.ipiv, w.perm, w.npad, w.info, (MwSync*)w.mw_sync, w.mw_timeout, w.mw_force_abort);
+            if (rpt1 <= 1) hipLaunchKernelGGL((lu_panel_mw_kernel<1>), dim3(w.G, W), block, 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, j0, m, W, w.ipiv, w.perm, w.npad, w.info, (MwSync*)w.mw_sync, w.mw_timeout, w.mw_force_abort);
+            else hipLaunchKernelGGL((lu_panel_mw_kernel<2>), dim3(w.G, W), block, 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, j0, m, W, w.ipiv, w.perm, w.npad, w.info, (MwSync*)w.mw_sync, w.mw_timeout, w.mw_force_abort);
             prof(w, KC_PANEL, 1, 8.0 * m * NBP * NBP / 2 * w.G, 16.0 * m * NBP * 2 * w.G);
             return;
         }
     }
 #endif
-    if (rpt <= 1) PANEL_IP(1, 4); else if (rpt <= 2) PANEL_IP(2, 4); else if (rpt <= 4) PANEL_IP(4, 4);
+    // MAUS_PANEL_PW8=1 (experiment): 8-column register sub-blocks where the rows per thread allow it (m <= 2048): 24 instead
+    // of 40 column reads per panel
+    static const int pw8 = [] { const char* e = getenv("MAUS_PANEL_PW8"); return e ? atoi(e) : 0; }();
+    if (pw8 && rpt <= 4) { if (rpt <= 1) PANEL_IP(1, 8); else if (rpt <= 2) PANEL_IP(2, 8); else PANEL_IP(4, 8); }
+    else if (rpt <= 1) PANEL_IP(1, 4); else if (rpt <= 2) PANEL_IP(2, 4); else if (rpt <= 4) PANEL_IP(4, 4);
     else if (rpt <= 8) PANEL_IP(8, 4); else PANEL_IP(16, 2);
 #undef PANEL_IP
     prof(w, KC_PANEL, 1, 8.0 * m * NBP * NBP / 2 * w.G, 16.0 * m * NBP * 8 * w.G);
@@ -816,16 +826,16 @@ void maus_lu_backsolve(const LuWs& w, c128* Wpop, long ldw, const int* d_slots, 
         (void)hipFuncSetAttribute((const void*)backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(backsolve_kernel, dim3(w.G), dim3(1024), shm, w.st, w.U, w.ldh, w.strideH, w.n, w.npad,
+    hipLaunchKernelGGL(backsolve_kernel, dim3(w.G), dim3(1024), shm, w.st, w.U, (long)LU_TW, w.strideH, w.n, w.npad,
                        Wpop, ldw, d_slots, xout_dense, w.flags);
     prof(w, KC_BACKSOLVE, 1, 4.0 * w.npad * w.npad * w.G, 8.0 * w.npad * w.npad * w.G);
 }
 
 void maus_build_h(const LuWs& w, const c128* A, const c128* d_shift, const double* d_psi, int rhs_mode,
-                  const c128* X, long ldx, const int* d_slots, const c128* bvec, int pert_mode, const double* d_U) {
+                  const c128* X, long ldx, const int* d_slots, const c128* bvec, int pert_mode, const double* d_U, int tiled) {
     prof(w, KC_BUILD, 0);
     hipLaunchKernelGGL(build_h_kernel, dim3(w.npad, w.G), dim3(256), 0, w.st, A, w.n, w.npad, w.ldh, w.strideH, w.H,
-                       d_shift, d_psi, rhs_mode, X, ldx, d_slots, bvec, pert_mode, d_U, w.flags);
+                       d_shift, d_psi, rhs_mode, X, ldx, d_slots, bvec, pert_mode, d_U, w.flags, tiled);
     prof(w, KC_BUILD, 1, 0, 32.0 * w.npad * w.ldh * w.G);
 }
 

@@ -14,6 +14,7 @@
 //     exactly as NumPy's legacy random_sample does ((a>>5)*2^26 + (b>>6)) / 2^53, and writes
 //     H = (A - lambda*delta) + (psi*delta + ((u-.5)*psi)*0.15) with NumPy's rounding order.
 #include "common.h"
+#include "luws.h"
 #include <cstdint>
 
 namespace {
@@ -111,7 +112,7 @@ build_h_mt_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long st
                   int rhs_mode, const c128* __restrict__ X, long ldx, const int* __restrict__ slots,
                   const c128* __restrict__ bvec,
                   const uint32_t* __restrict__ states /* [G][S][2][624] */, const int* __restrict__ extra /* [G][S][2] */,
-                  const int* __restrict__ rpos /* [G][S][2] */, long E, int* __restrict__ flags)
+                  const int* __restrict__ rpos /* [G][S][2] */, long E, int* __restrict__ flags, int tiled)
 {
     __shared__ uint32_t blk[2][2][MTN];      // [stream][parity][word]
     __shared__ double ring[2][RING];
@@ -121,6 +122,8 @@ build_h_mt_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long st
     const int s = tid / HALF, lt = tid - s * HALF;            // stream id, thread within the stream group
     const long gi = ((long)g * S + sb) * 2;                   // index of this workgroup's first generator
     c128* H = Hg + (long)g * strideH;
+    // element (i, j): row-major with leading dimension ldh (GMRES operand) or tile-major (LU workspace, luws.h)
+    auto hidx = [&](int i, int j) -> long { return tiled ? lu_tix(npad, i, j) : (long)i * ldh + j; };
     const c128 lam = shift[g];
     const double ps = psi[g];
     bool bad = false;
@@ -132,11 +135,11 @@ build_h_mt_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long st
             c128 v = cmake(0.0, 0.0);
             if (j < npad) { if (i == j) v.x = 1.0; }
             else if (j == npad && i < n) { v = (rhs_mode == 0) ? X[(long)slots[g] * ldx + i] : bvec[i]; bad |= !cfinite(v); }
-            H[(long)i * ldh + j] = v;
+            H[hidx(i, j)] = v;
         }
         for (long e = tid; e < (long)(npad - n) * n; e += GT) {            // pad rows, columns 0..n
             const int i = n + (int)(e / n), j = (int)(e - (long)(i - n) * n);
-            H[(long)i * ldh + j] = cmake(0.0, 0.0);
+            H[hidx(i, j)] = cmake(0.0, 0.0);
         }
     }
 
@@ -224,7 +227,7 @@ build_h_mt_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long st
                     h.y = __dadd_rn(a.y, pi);
                 }
                 bad |= !cfinite(h);
-                H[(long)i * ldh + j] = h;
+                H[hidx(i, j)] = h;
             }
         }
         done = hi;
@@ -244,7 +247,7 @@ void maus_mt_jump(hipStream_t st, uint32_t* states, const int* sel, int nsel, co
 }
 void maus_build_h_mt(hipStream_t st, const c128* A, int n, int npad, long ldh, long strideH, c128* H, int G, int S, long E,
                      const c128* d_shift, const double* d_psi, int rhs_mode, const c128* X, long ldx, const int* d_slots,
-                     const c128* bvec, const uint32_t* states, const int* extra, const int* rpos, int* flags) {
+                     const c128* bvec, const uint32_t* states, const int* extra, const int* rpos, int* flags, int tiled) {
     hipLaunchKernelGGL(build_h_mt_kernel, dim3(S, G), dim3(GT), 0, st, A, n, npad, ldh, strideH, H, d_shift, d_psi, rhs_mode,
-                       X, ldx, d_slots, bvec, states, extra, rpos, E, flags);
+                       X, ldx, d_slots, bvec, states, extra, rpos, E, flags, tiled);
 }

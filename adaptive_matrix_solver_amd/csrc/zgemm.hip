@@ -31,15 +31,24 @@
 
 namespace {
 
-template <int BM, int BN, int BK, int WM, int WN, int BLAY, bool CONJA, bool CONJB, bool PIPE, int MINW, bool M3 = false>
+// TILED (LU workspace, luws.h): A, B and C are whole matrices stored tile-major -- tiles of 64 columns, the `lda` (= ldb = ldc)
+// rows of a tile contiguous at 64 elements each -- and the operands are the sub-blocks
+//   A[a_rows[m]][tcol.x + k],  B[tcol.y + k][tcol.z + n],  C[c_rows[m]][tcol.z + n]        (tcol.x, .y multiples of 16).
+// A K-tile of 16 columns and a 16-column C block never straddle a tile, so inside a tile everything is row-major with a
+// leading dimension of 64 and only the tile base moves.
+struct TCol { int x, y, z; };
+__device__ __forceinline__ long tile_off(long rows, int col) { return ((long)(col >> 6) * rows << 6) + (col & 63); }
+
+template <int BM, int BN, int BK, int WM, int WN, int BLAY, bool CONJA, bool CONJB, bool PIPE, int MINW, bool M3 = false, bool TILED = false>
 __global__ void __launch_bounds__(64 * WM * WN, MINW)
 zgemm_kernel(int M, int N, int K,
              const c128* __restrict__ Ag, long lda, long strideA,
              const c128* __restrict__ Bg, long ldb, long strideB,
              c128* __restrict__ Cg, long ldc, long strideC,
              double alpha, int beta, int tiles_n, int nwg,
-             const int* __restrict__ a_rows, const int* __restrict__ c_rows, long rows_stride)
+             const int* __restrict__ a_rows, const int* __restrict__ c_rows, long rows_stride, TCol tcol)
 {
+    static_assert(!TILED || (BLAY == 0 && !CONJA && !CONJB && BK == 16), "tiled operands: plain layout, K-tiles of 16");
     constexpr int NT = 64 * WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
     constexpr int MB = WTM / 16, NB = WTN / 16;      // 16x16 blocks per wave
@@ -117,17 +126,18 @@ zgemm_kernel(int M, int N, int K,
     for (int i = 0; i < A_PER; ++i) {
         int r = tid / BK + i * (NT / BK);
         int gm = min(m0 + r, M - 1);
-        pa[i] = A + (long)(a_rows ? a_rows[gm] : gm) * lda;
+        pa[i] = A + (long)(a_rows ? a_rows[gm] : gm) * (TILED ? 64 : lda);
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
-        if (BLAY == 0) { int gn = min(n0 + tid % BN, N - 1); pb[i] = B + gn; }
+        if (BLAY == 0) { int gn = min(n0 + tid % BN, N - 1); pb[i] = B + (TILED ? tile_off(ldb, tcol.z + gn) + (long)tcol.y * 64 : (long)gn); }
         else { int gn = min(n0 + tid / BK + i * (NT / BK), N - 1); pb[i] = B + (long)gn * ldb; }
     }
+    const long ldb_e = TILED ? 64 : ldb;             // B row step inside the operand
     // plain layout: pb[i] points at this thread's B row for k0 = 0, so the per-tile step (k0 * ldb) is wave-uniform
     if (BLAY == 0) {
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) pb[i] += (long)(tid / BN + i * (NT / BN)) * ldb;
+        for (int i = 0; i < B_PER; ++i) pb[i] += (long)(tid / BN + i * (NT / BN)) * ldb_e;
     }
     // The loads only LOAD: zeroing the K edge and conjugation happen when the registers are written to
     // LDS one K-tile later.  (Touching the values here makes the compiler wait for the loads right away,
@@ -135,16 +145,18 @@ zgemm_kernel(int M, int N, int K,
     int kload = 0;                                   // k0 of the tile held in ra / rb
     auto load_tiles = [&](int k0) {
         kload = k0;
+        const long ta = TILED ? tile_off(lda, tcol.x + k0) : 0;          // wave-uniform: the K-tile's place in its 64-column tile
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int gk = k0 + (tid & (BK - 1));
-            ra[i] = pa[i][KEDGE ? min(gk, K - 1) : gk];
+            if (TILED) ra[i] = pa[i][ta + (tid & (BK - 1))];
+            else ra[i] = pa[i][KEDGE ? min(gk, K - 1) : gk];
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             if (BLAY == 0) {
                 const int kr = tid / BN + i * (NT / BN);
-                if (!KEDGE) rb[i] = pb[i][(long)k0 * ldb];
+                if (!KEDGE || TILED) rb[i] = pb[i][(long)k0 * ldb_e];
                 else rb[i] = pb[i][(long)(min(k0 + kr, K - 1) - kr) * ldb];
             } else {
                 int gk = k0 + (tid & (BK - 1));
@@ -285,7 +297,8 @@ zgemm_kernel(int M, int N, int K,
             for (int r = 0; r < 4; ++r) {
                 const int gm = m0 + wm * WTM + i * 16 + (lane >> 4) + 4 * r;
                 const int cm = min(gm, M - 1), cn = min(gn, N - 1);
-                off[r] = (long)(c_rows ? c_rows[cm] : cm) * ldc + cn;
+                off[r] = TILED ? (long)(c_rows ? c_rows[cm] : cm) * 64 + tile_off(ldc, tcol.z + cn)
+                               : (long)(c_rows ? c_rows[cm] : cm) * ldc + cn;
                 cold[r] = cmake(0.0, 0.0);
                 if (beta) cold[r] = C[off[r]];
             }
@@ -316,14 +329,14 @@ zgemm_kernel(int M, int N, int K,
 //   B image [8 k][32 n]  (512 B per k-row): natural order; the fragment read b = B[k = lane>>4][col = lane&15] is 16
 //       consecutive elements of one row.
 // ---------------------------------------------------------------------------------------
-template <int NST, int MINW, int MB, int NB>
+template <int NST, int MINW, int MB, int NB, bool TILED = false>
 __global__ void __launch_bounds__(256, MINW)
 zgemm3m_dma_kernel(int M, int N, int K,
                    const c128* __restrict__ Ag, long lda, long strideA,
                    const c128* __restrict__ Bg, long ldb, long strideB,
                    c128* __restrict__ Cg, long ldc, long strideC,
                    double alpha, int beta, int tiles_n, int nwg,
-                   const int* __restrict__ a_rows, const int* __restrict__ c_rows, long rows_stride)
+                   const int* __restrict__ a_rows, const int* __restrict__ c_rows, long rows_stride, TCol tcol)
 {
     constexpr int WN = 2, BM = 2 * 16 * MB, BN = WN * 16 * NB, BKS = 8;      // 2 x 2 waves, wave tile (16 MB) x (16 NB)
     constexpr int A_ST = BM * BKS, B_ST = BKS * BN;            // elements per stage
@@ -362,24 +375,27 @@ zgemm3m_dma_kernel(int M, int N, int K,
         const int r = (A_PW * wave + j) * 8 + (lane >> 3);
         const int kk = (lane & 7) ^ ((r >> 1) & 7);
         const int gm = min(m0 + r, M - 1);
-        srcA[j] = A + (long)(a_rows ? a_rows[gm] : gm) * lda + kk;
+        srcA[j] = A + (long)(a_rows ? a_rows[gm] : gm) * (TILED ? 64 : lda) + kk;
     }
     const c128* srcB[B_PW];
+    const long ldb_e = TILED ? 64 : ldb;
 #pragma unroll
     for (int j = 0; j < B_PW; ++j) {
         const int e = (B_PW * wave + j) * 64 + lane;             // element of the [8][BN] image
-        srcB[j] = B + (long)(e / BN) * ldb + min(n0 + (e % BN), N - 1);
+        const int gn = min(n0 + (e % BN), N - 1);
+        srcB[j] = B + (long)(e / BN) * ldb_e + (TILED ? tile_off(ldb, tcol.z + gn) + (long)tcol.y * 64 : (long)gn);
     }
 
     auto issue = [&](int st, int k0) {
         c128* As = smem + st * (A_ST + B_ST);
         c128* Bs = As + A_ST;
+        const long ta = TILED ? tile_off(lda, tcol.x + k0) : (long)k0;     // wave-uniform; 8 consecutive k never leave a tile
 #pragma unroll
         for (int j = 0; j < A_PW; ++j)
-            __builtin_amdgcn_global_load_lds((const void*)(srcA[j] + k0), (__attribute__((address_space(3))) void*)(As + (A_PW * wave + j) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(srcA[j] + ta), (__attribute__((address_space(3))) void*)(As + (A_PW * wave + j) * 64), 16, 0, 0);
 #pragma unroll
         for (int j = 0; j < B_PW; ++j)
-            __builtin_amdgcn_global_load_lds((const void*)(srcB[j] + (long)k0 * ldb), (__attribute__((address_space(3))) void*)(Bs + (B_PW * wave + j) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(srcB[j] + (long)k0 * ldb_e), (__attribute__((address_space(3))) void*)(Bs + (B_PW * wave + j) * 64), 16, 0, 0);
     };
 
     d4 cre[MB][NB], cim[MB][NB], c3[MB][NB];
@@ -450,7 +466,8 @@ zgemm3m_dma_kernel(int M, int N, int K,
             for (int r = 0; r < 4; ++r) {
                 const int gm = m0 + wm * 16 * MB + i * 16 + (lane >> 4) + 4 * r;
                 const int cm = min(gm, M - 1), cn = min(gn, N - 1);
-                off[r] = (long)(c_rows ? c_rows[cm] : cm) * ldc + cn;
+                off[r] = TILED ? (long)(c_rows ? c_rows[cm] : cm) * 64 + tile_off(ldc, tcol.z + cn)
+                               : (long)(c_rows ? c_rows[cm] : cm) * ldc + cn;
                 cold[r] = cmake(0.0, 0.0);
                 if (beta) cold[r] = C[off[r]];
             }
@@ -466,16 +483,16 @@ zgemm3m_dma_kernel(int M, int N, int K,
         }
 }
 
-template <int NST, int MINW, int MB, int NB>
+template <int NST, int MINW, int MB, int NB, bool TILED = false>
 void launch_dma(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA, const c128* B, long ldb, long sB,
                 c128* C, long ldc, long sC, double alpha, int beta, int batch, int, bool, bool,
-                const int* a_rows, const int* c_rows, long rows_stride)
+                const int* a_rows, const int* c_rows, long rows_stride, TCol tcol = TCol{0, 0, 0})
 {
     constexpr int BM = 32 * MB, BN = 32 * NB;
     int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     int nwg = tiles_m * tiles_n;
-    hipLaunchKernelGGL((zgemm3m_dma_kernel<NST, MINW, MB, NB>), dim3(nwg, batch), dim3(256), 0, st,
-                       M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows, rows_stride);
+    hipLaunchKernelGGL((zgemm3m_dma_kernel<NST, MINW, MB, NB, TILED>), dim3(nwg, batch), dim3(256), 0, st,
+                       M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows, rows_stride, tcol);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool PIPE, int MINW>
@@ -487,7 +504,7 @@ void launch_cfg(hipStream_t st, int M, int N, int K, const c128* A, long lda, lo
     int nwg = tiles_m * tiles_n;
     dim3 grid(nwg, batch), block(64 * WM * WN);
 #define LAUNCH(BL, CA, CB) hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WM, WN, BL, CA, CB, PIPE, MINW>), grid, block, 0, st, \
-        M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows, rows_stride)
+        M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows, rows_stride, TCol{0, 0, 0})
     if (blay == 0) {
         if (!conja && !conjb) LAUNCH(0, false, false);
         else if (!conja && conjb) LAUNCH(0, false, true);
@@ -503,15 +520,15 @@ void launch_cfg(hipStream_t st, int M, int N, int K, const c128* A, long lda, lo
 }
 
 // plain-layout-only instantiation (LU trailing updates): one kernel per tile shape instead of eight
-template <int BM, int BN, int BK, int WM, int WN, bool PIPE = false, int MINW = 4, bool M3 = false>
+template <int BM, int BN, int BK, int WM, int WN, bool PIPE = false, int MINW = 4, bool M3 = false, bool TILED = false>
 void launch_lu_only(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA, const c128* B, long ldb, long sB,
                     c128* C, long ldc, long sC, double alpha, int beta, int batch, int, bool, bool,
-                    const int* a_rows, const int* c_rows, long rows_stride)
+                    const int* a_rows, const int* c_rows, long rows_stride, TCol tcol = TCol{0, 0, 0})
 {
     int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     int nwg = tiles_m * tiles_n;
-    hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WM, WN, 0, false, false, PIPE, MINW, M3>), dim3(nwg, batch), dim3(64 * WM * WN), 0, st,
-                       M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows, rows_stride);
+    hipLaunchKernelGGL((zgemm_kernel<BM, BN, BK, WM, WN, 0, false, false, PIPE, MINW, M3, TILED>), dim3(nwg, batch), dim3(64 * WM * WN), 0, st,
+                       M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows, rows_stride, tcol);
 }
 
 }  // namespace
@@ -575,7 +592,38 @@ void maus_zgemm_launch_rows(hipStream_t st, int M, int N, int K, const c128* A, 
     }
     // 4M (population matvecs, Hermitian / SVD products, MAUS_GEMM_3M=0): 64x64 tiles, 32x32 wave tile.
     // With the next K-tile genuinely in flight during the MFMAs this needs ~160 VGPRs: three workgroups per CU.
+    // A population of a few hundred candidates against an n x n matrix gives few such tiles (M = 512, N = 2048: 256 -- one
+    // workgroup on each CU where three fit; M = 300, N = 4096: 320): below two tiles per CU the tile shrinks to 32 x 64 /
+    // 32 x 32 so that the grid covers the chip (MAUS_POPGEMM_TILE = 0 / 1 / 2 forces 64x64 / 32x64 / 32x32).
+    static const int pop_tile = [] { const char* e = getenv("MAUS_POPGEMM_TILE"); return e ? atoi(e) : -1; }();
+    const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * batch;
+    int tile = pop_tile;
+    if (tile < 0) tile = (t64 >= 512 || M <= 16) ? 0 : ((long)((M + 31) / 32) * ((N + 63) / 64) * batch >= 512 ? 1 : 2);
+    if (tile == 1) { launch_cfg<32, 64, 16, 1, 4, false, 4>(ARGS); return; }
+    if (tile == 2) { launch_cfg<32, 32, 16, 2, 2, false, 4>(ARGS); return; }
     launch_cfg<64, 64, 16, 2, 2, false, 3>(ARGS);
+#undef ARGS
+}
+
+// LU trailing update on the tile-major workspace (luws.h):  H[rows[m]][ccol + n] -= H[rows[m]][acol + k] * U[brow + k][ccol + n]
+// for m < M, n < N, k < K, all `batch` matrices (element stride `stride`, `nrows` rows per 64-column tile); rows = the LU's
+// per-matrix row permutation (rows_stride apart).  Same kernels and dispatch rule as the plain-layout path above.
+void maus_zgemm_launch_lu(hipStream_t st, int M, int N, int K, const c128* H, const c128* U, c128* Hc, long nrows, long stride,
+                          int acol, int brow, int ccol, int batch, const int* rows, long rows_stride)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return;
+    static const int dma_kmin = [] { const char* e = getenv("MAUS_GEMM_DMA_KMIN"); return e ? atoi(e) : 64; }();
+    const TCol tc{acol, brow, ccol};
+#define ARGS st, M, N, K, H, nrows, stride, U, nrows, stride, Hc, nrows, stride, -1.0, 1, batch, 0, false, false, rows, rows, rows_stride, tc
+    if (N <= 16) { launch_lu_only<128, 16, 16, 4, 1, false, 4, false, true>(ARGS); return; }
+    if (M <= 16) { launch_lu_only<16, 128, 16, 1, 4, false, 3, false, true>(ARGS); return; }
+    if (M > 32 && (K % 8) == 0 && K >= dma_kmin) {
+        if (M >= 1536 && N >= 1536) launch_dma<2, 3, 2, 2, true>(ARGS);      // 64 x 64 tiles, three workgroups per CU
+        else launch_dma<2, 5, 2, 1, true>(ARGS);
+        return;
+    }
+    if (M <= 32) { launch_lu_only<32, 64, 16, 1, 4, false, 4, true, true>(ARGS); return; }
+    launch_lu_only<64, 32, 16, 2, 2, false, 4, true, true>(ARGS);
 #undef ARGS
 }
 

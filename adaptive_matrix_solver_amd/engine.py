@@ -518,6 +518,9 @@ class DeviceEngine:
     def _hermitian(self, cands, A):
         from .solver import SolutionCandidate
         S = SolutionCandidate.State
+        if self._eig_cache is not None and self._eig_cache[0] is not A and self._eig_cache[0].shape == A.shape \
+                and np.array_equal(self._eig_cache[0], A):
+            self._eig_cache = (A, self._eig_cache[1])     # another solver on the same engine with an equal matrix: V is still resident
         if self._eig_cache is None or self._eig_cache[0] is not A:
             evals, err = self._eigh_once(A)
             if evals is None:

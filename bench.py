@@ -103,13 +103,207 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The other BASELINE.json configurations: same JSON schema, the roofline of THAT configuration's
+# dominant kernel, the oracle timed on the same workload.  The timed loop bodies start at iteration 1 of a fresh
+# population (warm-up runs on a scratch population of the same engine: workspace, eigendecomposition, tuned streams).
+# ---------------------------------------------------------------------------------------------------------------------
+OTHER = {
+    "c2": dict(n=1024, pop=256, steps=10, kind="eig", what="1024x1024 dense non-Hermitian eig (complex128 Ginibre/sqrt(n)), direct-LU path"),
+    "c3": dict(n=4096, pop=512, steps=4, kind="lin", what="4096x4096 linear system diag(10^U(0,7) e^{2 pi i U}) + 0.1 Ginibre/sqrt(n) (cond ~1e7, "
+                                                          "'Fragile': GMRES preferred), stuck_counter = 2 preset before every step so that the "
+                                                          "Jacobi preconditioner is active (AMS:65-72)"),
+    "c4": dict(n=8192, pop=128, steps=3, kind="herm", what="8192x8192 Hermitian eig (B+B^H)/2, Hermitian shortcut (AMS:155-181), one GPU's share "
+                                                            "(128) of the 1024 candidates BASELINE.json shards 8 ways"),
+    "c5": dict(n=2048, pop=512, steps=20, kind="svd", what="2048x2048 complex SVD power step on U diag(logspace(0,-8)) V^H (cond 1e8)"),
+}
+
+
+def _oracle_baseline(kind, A, b, n, budget_s, max_steps):
+    """cpu_baseline of a side configuration: the oracle's candidate_step on the same matrix, bounded."""
+    from oracle import maus_oracle as orc
+    import scipy
+    try:
+        from threadpoolctl import threadpool_info
+        pools = threadpool_info()
+        threads = max([p.get("num_threads", 1) for p in pools] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    st_np, st_py = np.random.get_state(), random.getstate()
+    orc.seed_all(4242)
+    okind = {"eig": orc.EIGENVALUE, "herm": orc.EIGENVALUE, "lin": orc.SOLVE_LINEAR_SYSTEM, "svd": orc.SVD}[kind]
+    strat = {"overall_psi_aggression_factor": 10.0 if kind == "lin" else (2.0 if kind == "svd" else 1.0), "max_psi_retries": 25,
+             "current_convergence_threshold": {"lin": 1e-4, "svd": 1e-5}.get(kind, 1e-8), "convergence_tolerance": 1e-8}
+    know = {"local_solver_preference": orc.GMRES if kind == "lin" else orc.DIRECT, "is_sparse_problem": False,
+            "is_hermitian": kind == "herm"}
+    ncand = 4 if kind != "herm" else 1
+    cands = [orc.new_candidate(A, okind, n) for _ in range(ncand)]
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        for c in cands:
+            if kind == "lin":
+                c.stuck = 2
+            if kind == "herm":
+                c.state = orc.EXPLORING                    # the reference decomposes the matrix again for every stepped candidate (AMS:161)
+            orc.candidate_step(c, A, b, strat, know, gmres_mode="rtol")
+            steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= max_steps or el / steps * (steps + ncand) > budget_s * 1.15:
+            break
+    el = time.perf_counter() - t0
+    np.random.set_state(st_np); random.setstate(st_py)
+    return {"value": steps / el, "unit": "candidate-steps/s", "cores": int(threads), "kind": "port",
+            "numpy": np.__version__, "scipy": scipy.__version__,
+            "sample": f"{steps} whole candidate steps of the NumPy/SciPy oracle (a restatement of the reference, checked bit for bit against "
+                      f"fixtures captured from it; not the reference itself) on the same matrix, {el:.1f} s, BLAS threads={threads}"}
+
+
+def run_other_config(args):
+    import scenarios
+    from adaptive_matrix_solver_amd.solver import MAUS_Solver, ProblemType, SolutionCandidate
+    cfg = OTHER[args.config]
+    n = cfg["n"] if args.n is None else args.n
+    P = cfg["pop"] if args.pop is None else args.pop
+    kind = cfg["kind"]
+    steps_k = args.steps if "--steps" in sys.argv else cfg["steps"]
+    warm_k = args.warmup if "--warmup" in sys.argv else 1
+    b = None
+    if kind == "eig":
+        A, PT = scenarios.ginibre(n, n), ProblemType.EIGENVALUE
+    elif kind == "lin":
+        (A, b), PT = scenarios.wide_diag_system(n, n, decades=7.0, offdiag=0.1), ProblemType.SOLVE_LINEAR_SYSTEM
+    elif kind == "herm":
+        A, PT = scenarios.hermitian(n, n), ProblemType.EIGENVALUE
+    else:
+        A, PT = scenarios.prescribed_svd(n, n, n, -8.0), ProblemType.SVD
+
+    def build(engine=None, diag=None):
+        np.random.seed(1234); random.seed(1234); SolutionCandidate._candidate_id_counter = 0
+        return MAUS_Solver(A, PT, b_vector=b, initial_num_candidates=P, global_convergence_tol=1e-8, quiet=True,
+                           engine=engine, diag_info=diag)
+
+    t0 = time.perf_counter()
+    scratch = build()
+    t_build = time.perf_counter() - t0
+    eng, ctx = scratch.engine, scratch.engine.ctx
+    info = ctx.device_info()
+    S = SolutionCandidate.State
+
+    def body(solver, it):
+        if kind == "lin":                        # Jacobi is built only for stuck_counter > 1 (AMS:65); a successful step decrements it
+            for c in solver.candidates:
+                if c.state not in (S.CONVERGED, S.RETIRED):
+                    c.stuck_counter = 2
+        return solver.loop_body(it)
+
+    t0 = time.perf_counter()
+    for it in range(warm_k):
+        body(scratch, it + 1)
+    ctx.sync()
+    t_warm = time.perf_counter() - t0                  # c4: contains the once-per-matrix eigh unless the diagnostics already did it
+    diag = dict(scratch.diag_info)
+    del scratch
+    solver = build(engine=eng, diag=diag)
+    gm = {"calls": 0, "cands": 0, "inner": 0}
+    if kind == "lin":
+        _g = ctx.gmres
+
+        def _gmres(*a, **k):
+            info_, inner, status = _g(*a, **k)
+            gm["calls"] += 1; gm["cands"] += len(inner); gm["inner"] += int(np.sum(inner))
+            return info_, inner, status
+        ctx.gmres = _gmres
+    ctx.sync()
+    per_step, steps_done = [], 0
+    t0 = time.perf_counter()
+    for it in range(steps_k):
+        ts = time.perf_counter()
+        act = body(solver, it + 1)
+        per_step.append({"ms": round((time.perf_counter() - ts) * 1e3, 3), "active": act})
+        steps_done += act
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    # one more population from iteration 1 with every launch bracketed by HIP events: per-class kernel times (untimed)
+    prof_solver = build(engine=eng, diag=diag)
+    ctx.profile_enable(1)
+    ctx.sync()
+    prof_steps = 0
+    for it in range(min(steps_k, 3)):
+        prof_steps += body(prof_solver, it + 1)
+    ctx.sync()
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    kernel_ms = {k: round(v["ms"], 3) for k, v in prof.items() if v["ms"] > 0}
+    tot_ms = sum(v["ms"] for v in prof.values())
+    # algorithmic flops per candidate step (SURVEY §8d)
+    if kind == "eig":
+        step_flops = 8.0 / 3.0 * n ** 3 + 24.0 * n * n
+    elif kind == "lin":
+        k_avg = gm["inner"] / max(1, gm["cands"])
+        step_flops = 8.0 * n * n * (k_avg + 2.0) + 16.0 * n * (k_avg * (k_avg + 1) / 2.0)
+    elif kind == "herm":
+        step_flops = 16.0 * n * n
+    else:
+        step_flops = 32.0 * n * n
+    # dominant kernel class of the profiled pass and its roofline
+    gemm_classes = [k for k in prof if k.startswith("zgemm")]
+    dom = max(prof, key=lambda k: prof[k]["ms"])
+    if kind != "eig":
+        dom = "zgemm" if prof["zgemm"]["ms"] >= 0.25 * tot_ms else dom
+    d = prof[dom]
+    if dom in gemm_classes:
+        use3m = kind == "eig" and os.environ.get("MAUS_GEMM_3M", "1") != "0"      # population GEMMs run the 4M kernel
+        exec_ratio = 0.75 if use3m else 1.0
+        alg = d["flops"] / max(1e-12, d["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": f"{dom} ({'3M LU trailing-update zgemm' if use3m else '4M population zgemm: A@X / A^H U / conj(X) V'}, v_mfma_f64_16x16x4_f64)",
+                "achieved": alg * exec_ratio, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg * exec_ratio / FP64_MFMA_PEAK_TFLOPS,
+                "achieved_algorithmic_8mnk": alg, "launches": d["launches"], "avg_launch_ms": d["ms"] / max(1, d["launches"]),
+                "traffic": None, "kernel_time_share": d["ms"] / tot_ms if tot_ms > 0 else None,
+                "algorithmic_bytes_per_launch": d["bytes"] / max(1, d["launches"]),
+                "hbm_GBs_at_algorithmic_bytes": d["bytes"] / max(1e-12, d["ms"] * 1e-3) / 1e9}
+    else:
+        gbs = d["bytes"] / max(1e-12, d["ms"] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "launches": d["launches"], "avg_launch_ms": d["ms"] / max(1, d["launches"]), "traffic": None,
+                "kernel_time_share": d["ms"] / tot_ms if tot_ms > 0 else None,
+                "algorithmic_bytes_per_launch": d["bytes"] / max(1, d["launches"])}
+    roof["source"] = (f"one untimed pass of {min(steps_k, 3)} loop bodies ({prof_steps} candidate steps) from iteration 1 with every launch "
+                      "bracketed by HIP events on the context's stream")
+    out = {
+        "metric": f"candidate-steps/sec, BASELINE.json configs[{int(args.config[1]) - 1}] ({args.config})",
+        "value": steps_done / elapsed, "unit": "candidate-steps/s", "n_gpus": 1, "steps": steps_k, "warmup": warm_k,
+        "ms_per_step": elapsed / max(1, steps_k) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{cfg['what']}, initial_num_candidates={P}", "n": n, "pop": P, "candidate_steps_timed": steps_done,
+                   "device": info["name"], "solver_build_s": round(t_build, 2), "warmup_s": round(t_warm, 2),
+                   "preferred_solver": solver.problem_knowledge.get("local_solver_preference"),
+                   "condition_number": float(solver.cond_number)},
+        "per_step": per_step,
+        "roofline": roof,
+        "kernel_ms_profiled_pass": kernel_ms,
+        "step_flops_algorithmic": step_flops,
+        "step_tflops": step_flops * steps_done / elapsed / 1e12,
+        "step_frac_of_mfma_peak": step_flops * steps_done / elapsed / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+    }
+    if kind == "lin":
+        out["gmres"] = {"calls": gm["calls"], "candidate_solves": gm["cands"], "inner_iterations_mean": gm["inner"] / max(1, gm["cands"])}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = _oracle_baseline(kind, A, b, n, args.cpu_budget, 64)
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", dest="n", type=int, default=4096, help="matrix order (default: the metric's 4096)")
-    ap.add_argument("--pop", type=int, default=256, help="initial_num_candidates (default: the metric's 256)")
+    ap.add_argument("--size", dest="n", type=int, default=None, help="matrix order (default: the configuration's; the metric's 4096 for c1)")
+    ap.add_argument("--pop", type=int, default=None, help="initial_num_candidates (default: the configuration's; the metric's 256 for c1)")
+    ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default="c1",
+                    help="c1 (default): the metric's configuration, n=4096 dense eig, pop=256.  The other BASELINE.json "
+                         "configurations, same JSON schema, single GPU: c2 = 1024x1024 eig / 256 candidates (batched LU); "
+                         "c3 = 4096x4096 linear system / 512 candidates, GMRES + Jacobi; c4 = 8192x8192 Hermitian eig (the "
+                         "shortcut; --pop defaults to one GPU's share of 1024, 128); c5 = 2048x2048 SVD cond 1e8 / 512 candidates")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-isolated", action="store_true", help="skip the untimed single-stream kernel-timing pass")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the pop = 32/64/128 side runs (N=1 only)")
@@ -162,6 +356,13 @@ def main():
     import scenarios
     from adaptive_matrix_solver_amd.solver import MAUS_Solver, ProblemType, SolutionCandidate
 
+    if args.config != "c1":
+        if world != 1:
+            sys.exit("bench.py: --config c2..c5 are single-GPU side benches (the driver's scaling run is the default config)")
+        run_other_config(args)
+        return
+    args.n = 4096 if args.n is None else args.n
+    args.pop = 256 if args.pop is None else args.pop
     n, P = args.n, args.pop
     A = scenarios.ginibre(n, n)                 # (G1 + i G2)/sqrt(n), seed n  
     device = local_rank if backend == "rccl" else 0

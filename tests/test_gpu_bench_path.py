@@ -211,14 +211,16 @@ LONG = {
     # loose tolerance: landscape energy falls below 0.8 while solutions are converged -> converged-base spawns
     # (AMS:539-547: random.choice, two random(), two rand(N) per spawn)
     "eig96_loose": (dict(kind="eig", build=("ginibre", 96, 96, None), P=80, iters=10, seed=5, tol=0.3), dict(pert_mode="mt19937")),
-    # small structured problem: 96 -> 366 active candidates over 34 iterations, first convergence at iteration 32.  (Not
-    # longer: a candidate drifting along this non-normal matrix amplifies the LAPACK-vs-device rounding difference by
-    # ~1.7x per iteration -- |dlambda| 2e-9 at iteration 32, 2.6e-8 at 37 -- so beyond ~35 iterations the two sides are
-    # different trajectories of the same chaotic map and step-by-step parity stops being a meaningful statement.)
+    # small structured problem: 96 -> 366 active candidates over 34 iterations, first convergence at iteration 32.  A
+    # candidate drifting along this non-normal matrix amplifies any rounding-level difference by ~1.65x per iteration: the
+    # ORACLE ITSELF, with one ulp added to the matrices it factorises, is 1e-9 away from its unperturbed run at iteration
+    # 32 and 1e-7 away at 37 (tests/test_rounding_sensitivity.py, tests/rounding.py) -- what the GPU run showed in round 2
+    # (2e-9 at 32, 2.6e-8 at 37).  The tolerance granted per iteration is derived from that envelope (rounding.granted_scale:
+    # 1.0 while a backward-error-sized perturbation stays below the base tolerance, i.e. for the first ~28 iterations).
     "lap8_p96": (dict(kind="eig", build=("laplace", 8, 8, False), P=96, iters=34, seed=7, tol=1e-7), dict(pert_mode="mt19937")),
 }
-# floating-point tolerances of test_gpu_step_parity.compare are for 10-25 iterations
-LONG_SCALE = {"lap8_p96": 30.0}
+# scenarios whose per-iteration tolerance scale comes from the perturbed-oracle envelope instead of being 1.0 throughout
+ENVELOPE_SCALED = {"lap8_p96"}
 
 
 def _active_view(rec):
@@ -245,8 +247,11 @@ def compare_long(ref, got, anorm, name, scale=1.0):
     import test_gpu_step_parity as sp
     nconv = [sum(1 for r in it["rows"] if r["state"] == orc.CONVERGED) for it in ref]
     strict = next((k for k, c in enumerate(nconv) if c >= 2), len(ref))
-    sp.compare(ref[:strict], got[:strict], anorm, name, scale=scale)
-    sp.compare([_active_view(r) for r in ref], [_active_view(g) for g in got], anorm, name + "-active", scale=scale)
+    scales = np.broadcast_to(np.asarray(scale, dtype=np.float64), (len(ref),))
+    for it in range(len(ref)):                       # one iteration at a time: the granted scale may depend on it
+        if it < strict:
+            sp.compare(ref[it:it + 1], got[it:it + 1], anorm, f"{name}@{it}", scale=float(scales[it]))
+        sp.compare([_active_view(ref[it])], [_active_view(got[it])], anorm, f"{name}-active@{it}", scale=float(scales[it]))
     for it, (r, g) in enumerate(zip(ref, got)):
         a, b = _converged_survivors(r), _converged_survivors(g)
         assert len(a) == len(b), f"{name} iter {it}: {len(a)} vs {len(b)} converged survivors"
@@ -268,7 +273,15 @@ def test_long_trajectory_many_active_candidates(name):
         with threadpool_limits(limits=2):                   # small matrices: BLAS threads only fight each other
             ref, anorm = sp.oracle_run(name, spec["iters"])
         got = sp.product_run(name, spec["iters"], **kw)
-        compare_long(ref, got, anorm, name, scale=LONG_SCALE.get(name, 1.0))
+        scale = 1.0
+        if name in ENVELOPE_SCALED:
+            import rounding
+            with threadpool_limits(limits=2):
+                env, _, first_order = rounding.envelope(name, spec["iters"], seeds=(1, 2, 3), ref=ref)
+            assert first_order >= spec["iters"], "the perturbed oracle itself loses the survivor order inside the horizon"
+            scale = rounding.granted_scale(env, sp.TOL_LAMBDA)
+            assert scale[:25].max() == 1.0 and scale.max() < 200.0, scale
+        compare_long(ref, got, anorm, name, scale=scale)
         active = [sum(1 for r in it["rows"] if r["state"] not in (orc.CONVERGED, orc.RETIRED)) for it in ref]
         assert min(active[:-1]) >= 64
         assert any(r["state"] == orc.CONVERGED for it in ref for r in it["rows"])
