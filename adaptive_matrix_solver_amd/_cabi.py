@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmaus_hip.so")
 SYMBOLS = [
     "maus_ctx_create", "maus_ctx_destroy", "maus_last_error", "maus_device_info", "maus_abi_version",
     "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get", "maus_pop_copy", "maus_pop_device_ptr", "maus_hist_append", "maus_hist_get", "maus_hist_clear", "maus_hist_generation",
-    "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_lu_reserve", "maus_lu_workspace_allocs", "maus_set_shared_device", "maus_lu_mw_aborts", "maus_lu_stream_choice", "maus_relax_normalise", "maus_residual",
+    "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_lu_reserve", "maus_lu_workspace_allocs", "maus_set_shared_device", "maus_lu_mw_aborts", "maus_relax_normalise", "maus_residual",
     "maus_svd_power_step", "maus_set_eigvecs", "maus_herm_match", "maus_gmres", "maus_gmres_pert", "maus_jacobi_check",
     "maus_profile_union_ms", "maus_gram", "maus_zgemm_host", "maus_zgemm_bench", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
     "maus_profile_enable", "maus_profile_read", "maus_sync", "maus_mt19937_jump",
@@ -84,7 +84,6 @@ def load_library():
         "maus_lu_workspace_allocs": ([vp], C.c_int),
         "maus_set_shared_device": ([vp, C.c_int], C.c_int),
         "maus_lu_mw_aborts": ([vp], C.c_int),
-        "maus_lu_stream_choice": ([vp, C.POINTER(C.c_int)], C.c_int),
         "maus_relax_normalise": ([vp, vp, C.c_int, vp, C.c_int, vp], C.c_int),
         "maus_residual": ([vp, C.c_int, vp, C.c_int, vp, vp, vp], C.c_int),
         "maus_svd_power_step": ([vp, vp, C.c_int, vp], C.c_int),
@@ -218,12 +217,6 @@ class Context:
     def lu_mw_aborts(self) -> int:
         """Batches that were repeated with one panel workgroup per matrix after a rendezvous time-out."""
         return int(self.lib.maus_lu_mw_aborts(self.h))
-
-    def lu_stream_choice(self):
-        """Sub-batch stream counts settled on for calls of 64-127, 128-191 and >= 192 solves (0: not settled yet)."""
-        out = (C.c_int * 3)()
-        self._ck(self.lib.maus_lu_stream_choice(self.h, out), "maus_lu_stream_choice")
-        return [int(v) for v in out]
 
     # -- problem data --------------------------------------------------------
     def set_matrix(self, A):

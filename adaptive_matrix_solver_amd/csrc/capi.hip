@@ -442,8 +442,8 @@ static LuWs make_ws(maus_ctx* c, int n, int G) {
     return w;
 }
 
-// up to three sub-batch streams, each sub-batch at least MAUS_LU_MIN_SUB (64) matrices (see maus_shifted_lu_solve)
-static int lu_stream_count() { const char* e = getenv("MAUS_LU_STREAMS"); int v = e ? atoi(e) : 3; return std::max(1, std::min(8, v)); }
+// one stream unless MAUS_LU_STREAMS asks for sub-batches, each at least MAUS_LU_MIN_SUB (64) matrices (see maus_shifted_lu_solve)
+static int lu_stream_count() { const char* e = getenv("MAUS_LU_STREAMS"); int v = e ? atoi(e) : 1; return std::max(1, std::min(8, v)); }
 
 static int ensure_lu_streams(maus_ctx* c, int n) {
     if (!c->ev_stage) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
@@ -498,7 +498,7 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
     maus_ctx::MtBuf& mb = c->mt_bufs[sbi];
     const int n = w.n;
     int s_override = 0;
-    { const char* e = getenv("MAUS_MT_SUBSTREAMS"); if (e) s_override = std::max(1, std::min(16, atoi(e))); }
+    { const char* e = getenv("MAUS_MT_SUBSTREAMS"); if (e && atoi(e) > 0) s_override = std::min(64, atoi(e)); }
     MausMtPlan& pl = c->mt_plan;
     const char* perr = nullptr;
     if (maus_mt_plan(d, n, first, g, s_override, &pl, &perr)) FAIL(c, perr ? perr : "maus_mt_plan failed");
@@ -511,7 +511,7 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
         HIPCHK(c, hipMalloc((void**)&mb.base, sizeof(uint32_t) * 624));
         mb.cap = cap;
     }
-    struct DevLevel { size_t off; int count; const int* taps; int ntap16; };
+    struct DevLevel { size_t off; int count; const int* taps; int ntap16; int src_off; };
     std::vector<DevLevel> levels;
     for (const MausMtPlan::Level& L : pl.levels) {
         auto it = c->mt_taps.find(L.J);
@@ -526,7 +526,7 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
             HIPCHK(c, hipMemcpy(dt, taps.data(), sizeof(int) * taps.size(), hipMemcpyHostToDevice));
             it = c->mt_taps.emplace(L.J, std::make_pair(dt, (int)(taps.size() / 16))).first;
         }
-        levels.push_back({L.off, L.count, it->second.first, it->second.second});
+        levels.push_back({L.off, L.count, it->second.first, it->second.second, L.src_off});
     }
     const std::vector<int>& hs = pl.hs;
     if (hs.size() > mb.int_cap) {
@@ -539,7 +539,7 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
     HIPCHK(c, hipMemcpyAsync(mb.ints, hs.data(), sizeof(int) * hs.size(), hipMemcpyHostToDevice, w.st));
     HIPCHK(c, hipStreamSynchronize(w.st));                       // staging (hs, d->key) is reusable from here on
     maus_mt_copy_states(w.st, mb.states, mb.base, ngen);
-    for (const DevLevel& L : levels) maus_mt_jump(w.st, mb.states, mb.ints + L.off, L.count, L.taps, L.ntap16);
+    for (const DevLevel& L : levels) maus_mt_jump(w.st, mb.states, mb.ints + L.off, L.count, L.taps, L.ntap16, L.src_off);
     const int* d_extra = mb.ints; const int* d_rpos = mb.ints + ngen;
     prof_tick(c, KC_BUILD, 0, 0, 0);
     maus_build_h_mt(w.st, c->A, n, w.npad, w.ldh, w.strideH, w.H, g, pl.S, (long)pl.E, c->d_c1 + lo, c->d_r1 + lo, rhs_mode, c->X, c->ldp,
@@ -563,7 +563,7 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
     const int nchunks = (count + c->Hg - 1) / c->Hg;
     const int Gmax = (count + nchunks - 1) / nchunks;
     const int nst = lu_stream_count();
-    if (ensure_lu_streams(c, std::max(nst, 3))) return -1;
+    if (ensure_lu_streams(c, nst)) return -1;
     std::vector<int> h_info(Gmax), h_flags(Gmax);
     for (int off = 0; off < count; off += Gmax) {
         const int G = std::min(Gmax, count - off);
@@ -577,46 +577,21 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             HIPCHK(c, hipMemcpyAsync(c->Upert, (const double*)pert_data + 2 * (size_t)n * n * off, ub, hipMemcpyHostToDevice, c->st));
             dU = c->Upert;
         }
-        // Sub-batches on their own streams: the bandwidth- and latency-bound phases of one sub-batch (panel, triangular
-        // solves, H build) run beside the MFMA-bound trailing updates of the others.  The gain is bounded -- a streaming
-        // kernel beside the zgemm hides ~30 % of its time at best (tools/probe_corun.hip) -- and more sub-batches mean
-        // smaller, less efficient launches.  How many pay depends on the batch size AND on the box: whole driver-shaped runs
-        // (n = 4096, pop = 256, 176-331 solves per step) gave 324.5 / 323.0 / 331.8 candidate-steps/s with 1 / 2 / 3 streams
-        // on one MI355X and 329.5 / 313.5 with 2 / 3 on another; at 139-165 solves per step two sub-batches beat three by
-        // 9 % (3.03 vs 3.30 ms per solve), at 79-109 two beat one by 2 %.  So the count is settled at run time, per
-        // batch-size class: the first calls of a class try the admissible counts once each (sub-batches of at least 32),
-        // the fastest per solve is kept.  Results do not depend on it (tests/test_gpu_bench_path.py: bit-equal).
-        // MAUS_LU_STREAMS=<n> (or MAUS_LU_TUNE=0) fixes the count instead: min(n, G / MAUS_LU_MIN_SUB).
+        // One stream by default.  MAUS_LU_STREAMS=<n> splits a batch into min(n, G / MAUS_LU_MIN_SUB) sub-batches on their own
+        // streams so that the bandwidth- and latency-bound phases of one (panel, triangular solves, H build) run beside the
+        // MFMA-bound trailing updates of the others.  That paid 0-2 % while those phases ran at 2.4-4 TB/s (round 2, where a
+        // run-time tuner picked the count per batch-size class); with the tile-major workspace they run at ~5 TB/s, the
+        // zgemm beside them loses more than they gain, and whole driver-shaped runs give 352 / 338 candidate-steps/s with
+        // 1 / 2 streams (profiles/r03_streams_fixed.txt) -- the tuner, which picked three from one noisy sample per count, is gone.
+        // Results do not depend on the split (tests/test_gpu_bench_path.py: bit-equal).
         static const int min_sub = [] { const char* e = getenv("MAUS_LU_MIN_SUB"); return e ? std::max(1, atoi(e)) : 64; }();
-        static const int tune_on = [] { const char* e = getenv("MAUS_LU_TUNE"); return e ? atoi(e) : 1; }();
-        int S, tune_cls = -1;
-        bool exploring = false;
-        if (getenv("MAUS_LU_STREAMS") || !tune_on) S = std::max(1, std::min(nst, G / min_sub));
-        else {
-            tune_cls = G >= 192 ? 2 : G >= 128 ? 1 : G >= 64 ? 0 : -1;
-            maus_ctx::LuTune& T = c->lu_tune;
-            if (tune_cls < 0) S = 1;
-            else if (T.calls++ == 0) S = std::max(1, std::min(nst, G / min_sub));   // first call: one-off set-up costs (streams, jump polynomials) would be timed
-            else if (T.choice[tune_cls]) S = T.choice[tune_cls];
-            else {
-                const int order[3] = {2, 3, 1};
-                const int smax = std::min(std::min(nst, 3), std::max(1, G / 32));
-                S = 0;
-                for (int o : order) if (o <= smax && !T.tried[tune_cls][o]) { S = o; break; }
-                if (S) exploring = true;
-                else {                                      // every admissible count tried: keep the fastest
-                    for (int o = 1; o <= 3; ++o) if (T.tried[tune_cls][o] && (!S || T.ms[tune_cls][o] < T.ms[tune_cls][S])) S = o;
-                    T.choice[tune_cls] = S = std::max(1, S);
-                }
-            }
-        }
+        const int S = std::max(1, std::min(nst, G / min_sub));
         // One more pass without the multi-workgroup panel if a rendezvous of it timed out (info = INT_MIN): its premise --
         // all workgroups of a matrix resident at once -- does not hold on a device that somebody else is using too.  The
         // pass rebuilds H from the same inputs, so the results are those of a context that never used that kernel.
         for (int pass = 0; pass < 2; ++pass) {
         HIPCHK(c, hipMemsetAsync(c->info, 0, sizeof(int) * G, c->st));
         HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int) * G, c->st));
-        const auto tune_t0 = std::chrono::steady_clock::now();
         if (S > 1) HIPCHK(c, hipEventRecord(c->ev_stage, c->st));
         std::vector<LuWs> wss;
         std::vector<int> los;
@@ -654,20 +629,10 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             if (pass == 0 && !c->mw_disabled) { c->mw_disabled = true; c->mw_aborts++; continue; }
             FAIL(c, "maus_shifted_lu_solve: internal error: LU panel rendezvous timed out (info < 0) and the batch could not be repeated");
         }
-        if (exploring && pass == 0) {
-            c->lu_tune.tried[tune_cls][S] = 1;
-            c->lu_tune.ms[tune_cls][S] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tune_t0).count() / G;
-        }
         break;
         }   // pass
         finish_status(G, h_info.data(), h_flags.data(), status + off);
     }
-    return 0;
-}
-
-int maus_lu_stream_choice(maus_ctx* c, int* choice_out) {
-    if (!c || !choice_out) return -1;
-    for (int k = 0; k < 3; ++k) choice_out[k] = c->lu_tune.choice[k];
     return 0;
 }
 

@@ -18,7 +18,7 @@ void maus_load_h(const LuWs& w, const c128* d_Ain, const c128* d_bin);
 int maus_lu_max_npad();
 size_t maus_lu_mw_sync_bytes();
 void maus_mt_copy_states(hipStream_t st, uint32_t* states, const uint32_t* base, int count);
-void maus_mt_jump(hipStream_t st, uint32_t* states, const int* sel, int nsel, const int* taps, int ntap16);
+void maus_mt_jump(hipStream_t st, uint32_t* states, const int* sel, int nsel, const int* taps, int ntap16, int src_off);
 int maus_mt_zero_tap();
 void maus_build_h_mt(hipStream_t st, const c128* A, int n, int npad, long ldh, long strideH, c128* H, int G, int S, long E,
                      const c128* d_shift, const double* d_psi, int rhs_mode, const c128* X, long ldx, const int* d_slots,
@@ -74,12 +74,9 @@ struct maus_ctx {
     std::vector<MtBuf> mt_bufs;
     std::map<uint64_t, std::pair<int*, int>> mt_taps;   // J -> (device tap list of x^J mod phi, #taps/16)
     MausMtPlan mt_plan;                                 // host plan + staging image of the current sub-batch (mtplan.cpp)
-    // sub-batch streams: bandwidth-bound phases (panel, swaps, trsm) of one sub-batch overlap the
+    // optional sub-batch streams (MAUS_LU_STREAMS > 1): bandwidth-bound phases of one sub-batch beside the
     // MFMA-bound trailing updates of another
     std::vector<hipStream_t> lu_st; std::vector<hipEvent_t> lu_done; hipEvent_t ev_stage = nullptr;
-    // Sub-batch stream count by batch-size class (64-127, 128-191, >= 192 solves), settled at run time: which count wins
-    // differs from one MI355X box to the next (maus_shifted_lu_solve)
-    struct LuTune { int choice[3] = {0, 0, 0}; int tried[3][4] = {}; double ms[3][4] = {}; long calls = 0; } lu_tune;
     hipStream_t prof_st = nullptr;
     // history store (SURVEY f-4): rows appended on the device, oldest chunks spilled to host memory beyond a byte budget
     struct HistChunk { c128* dev = nullptr; c128* host = nullptr; long rows = 0; long cap = 0; };

@@ -621,17 +621,20 @@ trsm_ip_kernel(const c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long
     c128* U = Ug + (long)blockIdx.y * strideH;
     if (threadIdx.x < TW) sp[threadIdx.x] = perm_g[(long)blockIdx.y * npad + j + threadIdx.x];
     __syncthreads();
+    // this thread's column first (registers), then the triangle (LDS): both gathers are in flight together -- issued behind
+    // the barrier that publishes the triangle, the column's loads waited out a second memory latency in every launch
+    const int col = c_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = col < c_hi;
+    const long tc = lu_tile_off(npad, live ? col : c_lo);
+    c128 x[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) x[i] = H[tc + (long)sp[i] * ld];
     for (int e = threadIdx.x; e < TW * TW; e += blockDim.x) {
         int r = e / TW, c = e % TW;                                // (j is a multiple of 16 only: a 32-wide block may straddle two tiles)
         sL[r][c] = H[lu_tile_off(npad, j + c) + (long)sp[r] * ld];
     }
     __syncthreads();
-    const int col = c_lo + blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= c_hi) return;
-    const long tc = lu_tile_off(npad, col);
-    c128 x[TW];
-#pragma unroll
-    for (int i = 0; i < TW; ++i) x[i] = H[tc + (long)sp[i] * ld];
+    if (!live) return;
 #pragma unroll
     for (int i = 1; i < TW; ++i)
 #pragma unroll
@@ -659,18 +662,39 @@ backsolve_kernel(const c128* __restrict__ Hg, long ld, long strideH, int n, int 
     bool bad = false;
     for (int i0 = npad - BSB; i0 >= 0; i0 -= BSB) {
         const int jt = i0 + BSB;          // tail starts here
-        // rhs_i = y_i - U[i, jt:] . x[jt:]  ; 16 waves x 2 rows
-        for (int rr = 0; rr < BSB / 16; ++rr) {
-            const int i = i0 + wave * (BSB / 16) + rr;
-            const c128* row = H + (long)i * ld;                    // tile-major (luws.h): + tile offset of the column
-            double sr = 0.0, si = 0.0;
-            for (int j = jt + lane; j < npad; j += 64) {
-                const c128 u = row[lu_tile_off(npad, j)], xv = sx[j];
-                sr = fma(u.x, xv.x, sr); sr = fma(-u.y, xv.y, sr);
-                si = fma(u.x, xv.y, si); si = fma(u.y, xv.x, si);
+        // rhs_i = y_i - U[i, jt:] . x[jt:]  ; 16 waves x 2 rows.  Both rows of a wave and four 64-column tiles are in
+        // flight together (eight independent loads per lane): with one row and one tile at a time a small batch -- one
+        // workgroup per matrix, few workgroups on the chip -- waited out every load's latency (5.6 ms per 32-solve call).
+        {
+            static_assert(BSB / 16 == 2, "two rows per wave");
+            const int ia = i0 + wave * 2;
+            const c128* ra = H + (long)ia * ld;                    // tile-major (luws.h): + tile offset of the column
+            const c128* rb = ra + ld;
+            double sar[2] = {0.0, 0.0}, sai[2] = {0.0, 0.0}, sbr[2] = {0.0, 0.0}, sbi[2] = {0.0, 0.0};
+            const int t_lo = jt >> 6, t_hi = (npad + 63) >> 6;
+#pragma unroll 2
+            for (int t = t_lo; t < t_hi; t += 2) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int j = ((t + p) << 6) + lane;
+                    if (j >= jt && j < npad) {
+                        const long off = ((long)(t + p) * npad << 6) + lane;
+                        const c128 ua = ra[off], ub = rb[off], xv = sx[j];
+                        sar[p] = fma(ua.x, xv.x, sar[p]); sar[p] = fma(-ua.y, xv.y, sar[p]);
+                        sai[p] = fma(ua.x, xv.y, sai[p]); sai[p] = fma(ua.y, xv.x, sai[p]);
+                        sbr[p] = fma(ub.x, xv.x, sbr[p]); sbr[p] = fma(-ub.y, xv.y, sbr[p]);
+                        sbi[p] = fma(ub.x, xv.y, sbi[p]); sbi[p] = fma(ub.y, xv.x, sbi[p]);
+                    }
+                }
             }
-            sr = wave_sum(sr); si = wave_sum(si);
-            if (lane == 0) { const c128 y = row[lu_tile_off(npad, npad)]; sR[i - i0] = cmake(y.x - sr, y.y - si); }
+            const double s0 = wave_sum(sar[0] + sar[1]), s1 = wave_sum(sai[0] + sai[1]);
+            const double s2 = wave_sum(sbr[0] + sbr[1]), s3 = wave_sum(sbi[0] + sbi[1]);
+            if (lane == 0) {
+                const long yo = lu_tile_off(npad, npad);
+                const c128 ya = ra[yo], yb = rb[yo];
+                sR[ia - i0] = cmake(ya.x - s0, ya.y - s1);
+                sR[ia - i0 + 1] = cmake(yb.x - s2, yb.y - s3);
+            }
         }
         for (int e = tid; e < BSB * BSB; e += blockDim.x) {
             int r = e / BSB, c = e % BSB;
@@ -771,9 +795,9 @@ static void lu_panel(const LuWs& w, int j0) {
         }
     }
 #endif
-    // MAUS_PANEL_PW8=1 (experiment): 8-column register sub-blocks where the rows per thread allow it (m <= 2048): 24 instead
-    // of 40 column reads per panel
-    static const int pw8 = [] { const char* e = getenv("MAUS_PANEL_PW8"); return e ? atoi(e) : 0; }();
+    // 8-column register sub-blocks where the rows per thread allow it (m <= 2048): 24 instead of 40 column reads per panel
+    // (33.0 vs 34.4 ms per 181-solve sweep, 37.5 vs 39.1 at 256; MAUS_PANEL_PW8=0: 4-column sub-blocks everywhere)
+    static const int pw8 = [] { const char* e = getenv("MAUS_PANEL_PW8"); return e ? atoi(e) : 1; }();
     if (pw8 && rpt <= 4) { if (rpt <= 1) PANEL_IP(1, 8); else if (rpt <= 2) PANEL_IP(2, 8); else PANEL_IP(4, 8); }
     else if (rpt <= 1) PANEL_IP(1, 4); else if (rpt <= 2) PANEL_IP(2, 4); else if (rpt <= 4) PANEL_IP(4, 4);
     else if (rpt <= 8) PANEL_IP(8, 4); else PANEL_IP(16, 2);

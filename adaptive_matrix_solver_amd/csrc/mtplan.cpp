@@ -2,9 +2,17 @@
 // NumPy stream (AMS:49: two rand(N,N) per dense attempt); each of its two draws is cut into S sub-streams of
 // ceil(N^2/S) elements.  Generator (k, sb, part) therefore starts at stream word
 //     t = pos + (draw index mm) * 2N^2 + 2 * sb * E,         mm = (lead + ord_k * wpc) / 2N^2 + part,
-// i.e. in block q = t / 624 at position t % 624.  q is reached as  m * dj + b * dj2  blocks by jump polynomials (binary
-// lifting: level i applies x^(624 * stride * 2^i) to the states whose index has bit i set) plus `extra` real block
-// regenerations inside the build kernel.
+// i.e. in block q = t / 624 at position t % 624.  q is reached as  m * dj + b * dj2  blocks by jump polynomials plus
+// `extra` real block regenerations inside the build kernel:
+//   * over the draw index m by binary lifting (level i applies x^(624 * dj * 2^i) to the states whose m has bit i set), on
+//     the first sub-stream of every draw only;
+//   * over the sub-stream index b by a doubling tree: level i computes the states with b in [2^i, 2^(i+1)) from the
+//     states with b - 2^i (one jump per generator; lifting every sub-stream on its own cost popcount(m) + popcount(b)
+//     jumps each, 13 launches of ~2900 jump workgroups = 22 ms at 181 candidates x 16 sub-streams).
+// dj and dj2 are the whole blocks a draw / a sub-stream is long, so `extra` stays a handful of blocks (round 2 jumped one
+// block short per step "so that a real regeneration follows": word 0 of a jumped state has correct low bits only if the
+// base state has a predecessor; a freshly seeded state (pos = 624) has not, but then t / 624 exceeds the jumped blocks
+// by at least one anyway, and every state NumPy reaches with pos < 624 has been regenerated at least once).
 #include "mtplan.h"
 #include <algorithm>
 
@@ -15,17 +23,19 @@ int maus_mt_plan(const maus_mt_desc* d, int n, int first, int g, int s_override,
     if (d->pos < 0 || d->pos > 624) return fail("maus_mt_desc: bad position");
     if (d->words_per_candidate % two_n2 || d->lead_words % two_n2 || d->words_per_candidate < 2 * two_n2 || !d->ordinals)
         return fail("maus_mt_desc: words_per_candidate / lead_words must be multiples of 2*n*n");
-    // sub-streams per draw: enough workgroups to cover the chip a few times, each at least ~64 blocks long
-    int S = std::max(1, std::min(8, 768 / std::max(1, g)));
+    // sub-streams per draw (one 4-wave workgroup each): a power of two (measured at 181 candidates: 8 -> 15.3 ms, 9 -> 18.5,
+    // 16 -> 16.5, 4 -> 21.9 per H build), enough of them to cover the chip a few times, each at least ~64 blocks long
+    int S = 1;
+    while (2 * S <= 16 && 2 * S * std::max(1, g) <= 2048) S *= 2;
     const uint64_t nn = (uint64_t)n * n;
     while (S > 1 && nn / S < 64 * 312) --S;
-    if (s_override > 0) S = std::max(1, std::min(16, s_override));
+    if (s_override > 0) S = std::max(1, std::min(64, s_override));
     const uint64_t E = (nn + S - 1) / S;                          // elements per sub-stream
     const int ngen = 2 * g * S;
     const uint64_t dblocks = two_n2 / 624;
-    const uint64_t dj = dblocks >= 2 ? dblocks - 1 : 0;          // jump stride (blocks) per draw; >= 1 real regeneration follows
+    const uint64_t dj = dblocks;                                 // jump stride (blocks) per draw
     const uint64_t sblocks = (2 * E) / 624;
-    const uint64_t dj2 = (S > 1 && sblocks >= 2) ? sblocks - 1 : 0;   // jump stride (blocks) per sub-stream
+    const uint64_t dj2 = (S > 1) ? sblocks : 0;                  // jump stride (blocks) per sub-stream
     std::vector<uint64_t> m(ngen), bsel(ngen);
     std::vector<int>& hs = out->hs;
     hs.assign(2 * (size_t)ngen, 0);
@@ -49,17 +59,21 @@ int maus_mt_plan(const maus_mt_desc* d, int n, int first, int g, int s_override,
             }
     }
     out->levels.clear();
-    auto plan = [&](const std::vector<uint64_t>& idx, uint64_t maxv, uint64_t stride_blocks) {
-        for (int bit = 0; stride_blocks && bit < 64 && (maxv >> bit); ++bit) {
-            const size_t off = hs.size();
-            for (int i = 0; i < ngen; ++i) if ((idx[i] >> bit) & 1ull) hs.push_back(i);
-            const int cnt = (int)(hs.size() - off);
-            if (!cnt) continue;
-            out->levels.push_back({off, cnt, 624ull * stride_blocks * (1ull << bit)});
-        }
-    };
-    plan(m, maxm, dj);
-    plan(bsel, maxb, dj2);
+    // lifting over m: on the first sub-stream of each draw when the tree below derives the others from it, else on all
+    for (int bit = 0; dj && bit < 64 && (maxm >> bit); ++bit) {
+        const size_t off = hs.size();
+        for (int i = 0; i < ngen; ++i) if (((m[i] >> bit) & 1ull) && (!dj2 || (i / 2) % S == 0)) hs.push_back(i);
+        const int cnt = (int)(hs.size() - off);
+        if (cnt) out->levels.push_back({off, cnt, 624ull * dj * (1ull << bit), 0});
+    }
+    // doubling tree over the sub-stream index: state(b) = x^(624 * dj2 * 2^i) state(b - 2^i) for 2^i <= b < 2^(i+1)
+    for (int bit = 0; dj2 && (1 << bit) < S; ++bit) {
+        const size_t off = hs.size();
+        for (int i = 0; i < ngen; ++i) { const int sb = (i / 2) % S; if (sb >= (1 << bit) && sb < (2 << bit)) hs.push_back(i); }
+        const int cnt = (int)(hs.size() - off);
+        if (cnt) out->levels.push_back({off, cnt, 624ull * dj2 * (1ull << bit), 2 << bit});
+    }
+    (void)maxb;
     out->S = S; out->E = E; out->ngen = ngen; out->dj = dj; out->dj2 = dj2;
     return 0;
 }

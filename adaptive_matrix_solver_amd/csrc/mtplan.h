@@ -15,7 +15,8 @@ struct MausMtPlan {
     // staging image for the device: extra[ngen] (real block regenerations after the jumps) | rpos[ngen] (position in the
     // block) | the selection list of every lifting level
     std::vector<int> hs;
-    struct Level { size_t off; int count; uint64_t J; };     // states hs[off .. off+count) are advanced by J words
+    // states[hs[off + i]] <- x^J applied to states[hs[off + i] - src_off]   (src_off = 0: in place)
+    struct Level { size_t off; int count; uint64_t J; int src_off; };
     std::vector<Level> levels;
 };
 

@@ -456,7 +456,6 @@ def main():
     prof = ctx.profile_read()
     ctx.profile_enable(False)
     ws_allocs = ctx.lu_workspace_allocations()
-    stream_choice = ctx.lu_stream_choice()
     # Isolated pass (untimed, rank 0 at N=1 only): one more step on a single stream with every launch bracketed, so
     # that each kernel has the GPU to itself -- in the timed region two sub-batch streams overlap and a kernel's
     # event-to-event time includes whatever the other stream ran beside it.
@@ -563,9 +562,7 @@ def main():
             "per_rank": per_rank,
             "per_step_summary": {"ms_per_candidate_step_median": round(float(np.median(ms_norm)), 4),
                                  "ms_per_candidate_step_max": round(float(np.max(ms_norm)), 4),
-                                 "lu_workspace_allocations_total": ws_allocs,
-                                 # sub-batch streams the library settled on for calls of 64-127 / 128-191 / >= 192 solves
-                                 "lu_sub_batch_streams_chosen": stream_choice},
+                                 "lu_workspace_allocations_total": ws_allocs},
             "roofline": {"bound": "mfma", "kernel": "zgemm3m_dma_kernel (LDS-DMA staged 3M zgemm, 64x64 / 64x32 tiles), K>=256 launches (LU trailing updates, v_mfma_f64_16x16x4_f64)",
                          # achieved / frac: real flops EXECUTED on the matrix pipe (3M: 6*M*N*K per complex GEMM) over the
                          # union of the launches' intervals; the algorithmic (8*M*N*K) rate is a side field
@@ -580,7 +577,7 @@ def main():
                          "flops_per_launch_algorithmic": g["flops"] / max(1, g["launches"]),
                          "kernel_time_share": ((g["ms"] / tot_ms) if tot_ms > 0 else None) if args.kernel_events == "all" else None,
                          "measured_mfma_f64_issue_rate_tflops": 77.9,
-                         "lu_streams": os.environ.get("MAUS_LU_STREAMS", f"settled at run time: {stream_choice} for 64-127 / 128-191 / >=192 solves per call"),
+                         "lu_streams": os.environ.get("MAUS_LU_STREAMS", "1"),
                          "isolated_single_stream_pass": None if iso is None else {
                              "matrices": iso_active,
                              "achieved_algorithmic_8mnk": iso["zgemm"]["flops"] / max(1e-9, iso["zgemm"]["ms"] * 1e-3) / 1e12,

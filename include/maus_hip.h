@@ -153,12 +153,6 @@ int maus_lu_workspace_allocs(maus_ctx* ctx);
 int maus_set_shared_device(maus_ctx* ctx, int shared);
 int maus_lu_mw_aborts(maus_ctx* ctx);
 
-/* Sub-batch stream counts this context settled on for calls of 64-127, 128-191 and >= 192 solves (choice_out[3]; 0 = not
- * settled yet).  maus_shifted_lu_solve splits a large batch into independent sub-batches on their own streams; which
- * count is fastest differs between boxes, so the first calls of each class time the admissible counts once.  Results do
- * not depend on the split (no reference counterpart: AMS:574-576 is one sequential loop). */
-int maus_lu_stream_choice(maus_ctx* ctx, int* choice_out);
-
 /* X[slot] <- (1-alpha) X[slot] + alpha W[slot]; norm_out = ||X||_2; if normalise and
  * norm > 1e-10: X *= 1/norm                                        AMS:280-285.
  * alpha_c128[count] complex.  Slots whose norm test fails are left un-normalised (the

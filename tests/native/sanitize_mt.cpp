@@ -46,7 +46,8 @@ int main() {
     // (2) the plan of a device sub-batch: every generator's start, reached by the planned jumps + `extra` regenerations,
     //     must be the state plain stepping reaches at that generator's first word
     struct Cfg { int n, g, first, pos, s_override; uint64_t wpc_mult, lead_mult; };
-    const Cfg cfgs[] = {{24, 5, 0, 624, 0, 2, 0}, {40, 9, 2, 17, 3, 4, 2}, {64, 33, 0, 600, 0, 2, 0}, {96, 3, 1, 1, 4, 2, 0}};
+    const Cfg cfgs[] = {{24, 5, 0, 624, 0, 2, 0}, {40, 9, 2, 17, 3, 4, 2}, {64, 33, 0, 600, 0, 2, 0}, {96, 3, 1, 1, 4, 2, 0},
+                        {96, 4, 0, 600, 7, 2, 0}, {48, 3, 1, 5, 16, 2, 1}, {128, 3, 0, 33, 13, 2, 0}, {128, 2, 0, 624, 16, 2, 0}};
     for (const Cfg& c : cfgs) {
         maus_mt_desc d; std::memset(&d, 0, sizeof d);
         uint32_t base[N]; seed(base, 12345u + (uint32_t)c.n); regen(base);
@@ -59,14 +60,15 @@ int main() {
         MausMtPlan pl; const char* err = nullptr;
         check(maus_mt_plan(&d, c.n, c.first, c.g, c.s_override, &pl, &err) == 0, err ? err : "maus_mt_plan failed");
         check(pl.ngen == 2 * c.g * pl.S && (int)pl.hs.size() >= 2 * pl.ngen, "plan: sizes");
-        // blocks each generator is advanced by the lifting levels
+        // blocks each generator is advanced by the levels, in order: lifting over the draw index in place (src_off = 0),
+        // then the doubling tree over the sub-stream index (state <- jump of the state src_off generators before it)
         std::vector<uint64_t> jumped(pl.ngen, 0);
         for (const auto& L : pl.levels) {
             check(L.J % 624 == 0 && L.off + (size_t)L.count <= pl.hs.size(), "plan: level bounds");
             for (int i = 0; i < L.count; ++i) {
                 const int gi = pl.hs[L.off + i];
-                check(gi >= 0 && gi < pl.ngen, "plan: generator index out of range");
-                if (gi >= 0 && gi < pl.ngen) jumped[gi] += L.J / 624;
+                check(gi >= 0 && gi < pl.ngen && gi - L.src_off >= 0, "plan: generator index out of range");
+                if (gi >= 0 && gi < pl.ngen && gi - L.src_off >= 0) jumped[gi] = jumped[gi - L.src_off] + L.J / 624;
             }
         }
         for (int k = 0; k < c.g; ++k)
@@ -76,7 +78,7 @@ int main() {
                     const uint64_t mm = (d.lead_words + (uint64_t)ords[c.first + k] * d.words_per_candidate) / two_n2 + part;
                     const uint64_t t = (uint64_t)d.pos + mm * two_n2 + 2ull * sb * pl.E;
                     check(jumped[gi] + (uint64_t)pl.hs[gi] == t / 624 && (uint64_t)pl.hs[pl.ngen + gi] == t % 624, "plan: block arithmetic");
-                    if (k < 2 && sb == pl.S - 1) {                    // and really: jump + regenerate == step
+                    if (k < 2 && (sb == pl.S - 1 || sb == pl.S / 2)) {   // and really: jump + regenerate == step
                         uint32_t a[N], b[N]; std::memcpy(a, base, sizeof a); std::memcpy(b, base, sizeof b);
                         for (uint64_t q = 0; q < t / 624; ++q) regen(a);
                         int32_t pb = 624;                             // key as a block boundary: J words = J/624 blocks

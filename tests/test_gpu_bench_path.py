@@ -46,7 +46,10 @@ class _env:
     def __enter__(self):
         self.old = {k: os.environ.get(k) for k in self.kv}
         for k, v in self.kv.items():
-            os.environ[k] = str(v)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
 
     def __exit__(self, *a):
         for k, v in self.old.items():
@@ -59,7 +62,7 @@ class _env:
 # ---------------------------------------------------------------------------------------------
 # the metric's configuration through the sub-batch streams: n = 4096, all 256 solves of a step at once
 # ---------------------------------------------------------------------------------------------
-def test_eig4096_pop256_two_streams_against_host_and_lapack(ctx):
+def test_eig4096_pop256_one_and_three_streams_against_host_and_lapack(ctx):
     import scipy.linalg as sla
     from adaptive_matrix_solver_amd._cabi import PERT_MT19937
     n, P = 4096, 256
@@ -76,8 +79,8 @@ def test_eig4096_pop256_two_streams_against_host_and_lapack(ctx):
     np.random.seed(4096)
     st = np.random.get_state()
     desc = (st, 4 * n * n, 0, np.arange(P, dtype=np.int32))
-    assert "MAUS_LU_STREAMS" not in os.environ                   # default sub-batch streams (85 + 85 + 86), as bench.py runs
-    status = ctx.shifted_lu_solve(slots, lam, psi, 0, PERT_MT19937, desc)
+    with _env(MAUS_LU_STREAMS=3):                               # three sub-batches (85 + 85 + 86) on their own streams
+        status = ctx.shifted_lu_solve(slots, lam, psi, 0, PERT_MT19937, desc)
     assert (status == 0).all()
     W = ctx.pop_get(2, slots, n)
     # (i) round trip H_k w_k = v_k for every candidate of both sub-batches (host GEMM)
@@ -85,8 +88,9 @@ def test_eig4096_pop256_two_streams_against_host_and_lapack(ctx):
     rel = np.linalg.norm(HW - V, axis=1) / np.linalg.norm(V, axis=1)
     bound = 1e-13 * np.linalg.norm(A, 1) * np.linalg.norm(W, axis=1) / np.linalg.norm(V, axis=1)
     assert (rel <= np.maximum(bound, 1e-12)).all(), (int(np.argmax(rel / np.maximum(bound, 1e-12))), rel.max())
-    # (ii) one stream instead of three: same bits for all 256 (the sub-batch offsets address the right matrices)
-    with _env(MAUS_LU_STREAMS=1):
+    # (ii) one stream (the default, as bench.py runs) instead of three: same bits for all 256 (the sub-batch offsets
+    # address the right matrices)
+    with _env(MAUS_LU_STREAMS=None):
         status1 = ctx.shifted_lu_solve(slots, lam, psi, 0, PERT_MT19937, desc)
         W1 = ctx.pop_get(2, slots, n)
     assert (status1 == 0).all()
@@ -106,12 +110,11 @@ def test_eig4096_pop256_two_streams_against_host_and_lapack(ctx):
         assert np.linalg.norm(W[k] - x1[0]) <= 1e-11 * np.linalg.norm(ref), k
 
 
-def test_stream_count_settles_at_run_time_and_results_do_not_depend_on_it():
-    """The number of sub-batch streams is chosen at run time per batch-size class (the first calls of a class time the
-    admissible counts).  Whatever is tried or chosen, every call returns the same bits; the choice is reported."""
+def test_results_do_not_depend_on_the_sub_batch_stream_split():
+    """One stream is the default; MAUS_LU_STREAMS=n splits a batch into sub-batches on their own streams.  Whatever the
+    split, every call returns the same bits."""
     from adaptive_matrix_solver_amd import Context
     from adaptive_matrix_solver_amd._cabi import PERT_MT19937
-    assert "MAUS_LU_STREAMS" not in os.environ and os.environ.get("MAUS_LU_TUNE", "1") != "0"
     n, P = 160, 230
     A = scenarios.ginibre(n, 77, None)
     rng = np.random.default_rng(5)
@@ -126,23 +129,18 @@ def test_stream_count_settles_at_run_time_and_results_do_not_depend_on_it():
         np.random.seed(9)
         st = np.random.get_state()
         outs = {}
-        for G in (230, 150, 100, 40):                       # classes >= 192, 128-191, 64-127, and below (always one stream)
-            sl = list(range(G))
-            desc = (st, 4 * n * n, 0, np.arange(G, dtype=np.int32))
-            for rep in range(6):
-                status = c.shifted_lu_solve(sl, lam[:G], psi[:G], 0, PERT_MT19937, desc)
-                assert (status == 0).all()
-                W = c.pop_get(2, sl, n)
-                if G in outs:
-                    assert np.array_equal(W, outs[G]), (G, rep)
-                outs[G] = W
-        choice = c.lu_stream_choice()
-        assert all(ch in (1, 2, 3) for ch in choice), choice
-        with _env(MAUS_LU_STREAMS=1):
-            for G in (230, 150, 100):
-                sl = list(range(G))
-                c.shifted_lu_solve(sl, lam[:G], psi[:G], 0, PERT_MT19937, (st, 4 * n * n, 0, np.arange(G, dtype=np.int32)))
-                assert np.array_equal(c.pop_get(2, sl, n), outs[G]), G
+        for streams in (None, 1, 2, 3):
+            with _env(MAUS_LU_STREAMS=streams):
+                for G in (230, 150, 100, 40):
+                    sl = list(range(G))
+                    desc = (st, 4 * n * n, 0, np.arange(G, dtype=np.int32))
+                    for rep in range(2):
+                        status = c.shifted_lu_solve(sl, lam[:G], psi[:G], 0, PERT_MT19937, desc)
+                        assert (status == 0).all()
+                        W = c.pop_get(2, sl, n)
+                        if G in outs:
+                            assert np.array_equal(W, outs[G]), (streams, G, rep)
+                        outs[G] = W
         HW = outs[230] @ A.T - (lam - psi)[:, None] * outs[230]
         assert np.linalg.norm(HW - V, axis=1).max() <= 1e-10 * np.linalg.norm(A, 1) * np.linalg.norm(outs[230], axis=1).max()
     finally:

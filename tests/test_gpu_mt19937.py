@@ -99,11 +99,12 @@ def test_trajectory_with_device_draws(name, iters):
 
 
 @pytest.mark.parametrize("n,count", [(96, 200), (64, 600)])
-def test_two_sub_batch_streams_keep_their_own_generator_state(ctx, n, count):
-    """>= 64 solves run as two sub-batches on two streams: each needs its own generator buffers (the host prepares
+def test_two_sub_batch_streams_keep_their_own_generator_state(ctx, n, count, monkeypatch):
+    """MAUS_LU_STREAMS=2: >= 128 solves run as two sub-batches on two streams: each needs its own generator buffers (the host prepares
     the second while the first still reads its states).  Same bits as the host-drawn path, with a psi large enough
     for the perturbation to reach the leading digits."""
     from adaptive_matrix_solver_amd._cabi import PERT_MT19937, PERT_UNIFORM
+    monkeypatch.setenv("MAUS_LU_STREAMS", "2")
     rng = np.random.default_rng(11)             # (64, 600): more solves than the 512-matrix workspace -> two chunks
     A = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) / np.sqrt(n)
     V = rng.standard_normal((count, n)) + 1j * rng.standard_normal((count, n))

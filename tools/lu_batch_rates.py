@@ -32,7 +32,7 @@ psi = np.full(P, 1e-20)
 np.random.seed(3)
 st = np.random.get_state()
 cap = ctx.lu_reserve(n, int(os.environ.get("LU_RESERVE", P)))
-print(f"# MAUS_PANEL_MW={os.environ.get('MAUS_PANEL_MW', '1')} MAUS_LU_STREAMS={os.environ.get('MAUS_LU_STREAMS', '3')} workspace capacity {cap}")
+print(f"# MAUS_PANEL_MW={os.environ.get('MAUS_PANEL_MW', '1')} MAUS_LU_STREAMS={os.environ.get('MAUS_LU_STREAMS', '1')} workspace capacity {cap}")
 for G in sizes:
     sl = list(range(G))
     desc = (st, 4 * n * n, 0, np.arange(G, dtype=np.int32))
