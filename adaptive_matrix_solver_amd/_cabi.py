@@ -18,7 +18,7 @@ SYMBOLS = [
     "maus_ctx_create", "maus_ctx_destroy", "maus_last_error", "maus_device_info", "maus_abi_version",
     "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get", "maus_pop_copy", "maus_pop_device_ptr", "maus_hist_append", "maus_hist_get", "maus_hist_clear", "maus_hist_generation",
     "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_lu_reserve", "maus_lu_workspace_allocs", "maus_set_shared_device", "maus_lu_mw_aborts", "maus_relax_normalise", "maus_residual",
-    "maus_svd_power_step", "maus_set_eigvecs", "maus_herm_match", "maus_gmres", "maus_gmres_pert", "maus_jacobi_check",
+    "maus_svd_power_step", "maus_svd_power_propose", "maus_svd_commit", "maus_set_eigvecs", "maus_herm_match", "maus_gmres", "maus_gmres_pert", "maus_jacobi_check",
     "maus_profile_union_ms", "maus_gram", "maus_zgemm_host", "maus_zgemm_bench", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
     "maus_profile_enable", "maus_profile_read", "maus_sync", "maus_mt19937_jump",
     "maus_device_count", "maus_comm_unique_id", "maus_comm_init", "maus_comm_destroy", "maus_comm_info",
@@ -87,6 +87,8 @@ def load_library():
         "maus_relax_normalise": ([vp, vp, C.c_int, vp, C.c_int, vp], C.c_int),
         "maus_residual": ([vp, C.c_int, vp, C.c_int, vp, vp, vp], C.c_int),
         "maus_svd_power_step": ([vp, vp, C.c_int, vp], C.c_int),
+        "maus_svd_power_propose": ([vp, vp, C.c_int, vp], C.c_int),
+        "maus_svd_commit": ([vp, vp, C.c_int], C.c_int),
         "maus_set_eigvecs": ([vp, vp, C.c_int], C.c_int),
         "maus_herm_match": ([vp, vp, C.c_int, vp, vp], C.c_int),
         "maus_gmres": ([vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_int, C.c_int, vp, vp, vp], C.c_int),
@@ -354,6 +356,18 @@ class Context:
         norms = np.empty((s.shape[0], 4), dtype=np.float64)
         self._ck(self.lib.maus_svd_power_step(self.h, _ptr(s), s.shape[0], _ptr(norms)), "maus_svd_power_step")
         return norms
+
+    def svd_power_propose(self, slots):
+        """The power step without its effect: norms as svd_power_step, proposed u / v left in POP_Y / POP_W."""
+        s = self._slots(slots)
+        norms = np.empty((s.shape[0], 4), dtype=np.float64)
+        self._ck(self.lib.maus_svd_power_propose(self.h, _ptr(s), s.shape[0], _ptr(norms)), "maus_svd_power_propose")
+        return norms
+
+    def svd_commit(self, slots):
+        s = self._slots(slots)
+        if s.shape[0]:
+            self._ck(self.lib.maus_svd_commit(self.h, _ptr(s), s.shape[0]), "maus_svd_commit")
 
     def herm_match(self, slots):
         s = self._slots(slots)

@@ -732,24 +732,44 @@ int maus_residual(maus_ctx* c, int kind, const int* slots, int count, const doub
     return 0;
 }
 
-int maus_svd_power_step(maus_ctx* c, const int* slots, int count, double* norms_out) {
-    if (!c->A || !c->X) FAIL(c, "maus_svd_power_step: matrix/population missing");
+// The step in two halves: propose leaves X / U alone (u_new in Y, v_new in W), commit copies them in for the candidates
+// the host accepts.  A collapse (AMS:229-232, 236-239) ends the speculative run at that candidate and the ones behind it
+// must be stepped again from their own vectors: with the proposal held back nothing has to be restored -- until round 3
+// the engine kept a host copy of every candidate's vectors for that, 400 MB over PCIe per loop body at BASELINE
+// configs[4] (6144 candidates x 2048), 57 % of its wall time.
+int maus_svd_power_propose(maus_ctx* c, const int* slots, int count, double* norms_out) {
+    if (!c->A || !c->X) FAIL(c, "maus_svd_power_propose: matrix/population missing");
     if (count == 0) return 0;
     if (upload_slots(c, slots, count)) return -1;
     // ||v_in||
     maus_launch_norm(c->st, c->X, c->ldp, c->d_slots, count, c->cols, c->d_r1, 4, 0);
-    // t = A v -> Y ; sigma1 = ||t|| ; u = t / (sigma1 > 1e-10 ? sigma1 : 1)
+    // t = A v -> Y ; sigma1 = ||t|| ; u = t / (sigma1 > 1e-10 ? sigma1 : 1), in place
     matvec_into_Y(c, c->X, count);
-    maus_launch_norm_scale(c->st, c->Y, c->U, c->ldp, c->d_slots, count, c->rows, c->d_r1, 4, 1);
-    maus_launch_norm(c->st, c->U, c->ldp, c->d_slots, count, c->rows, c->d_r1, 4, 2);
-    // s = A^H u -> W ; sigma2 = ||s|| ; v = s / (sigma2 > 1e-10 ? sigma2 : 1)
+    maus_launch_norm_scale(c->st, c->Y, c->Y, c->ldp, c->d_slots, count, c->rows, c->d_r1, 4, 1);
+    maus_launch_norm(c->st, c->Y, c->ldp, c->d_slots, count, c->rows, c->d_r1, 4, 2);
+    // s = A^H u -> W ; sigma2 = ||s|| ; v = s / (sigma2 > 1e-10 ? sigma2 : 1), in place
     { ProfScope ps(c, KC_GEMM, 8.0 * count * c->rows * c->cols, 16.0 * (double)c->rows * c->cols);
-      maus_zgemm_launch_idx(c->st, count, c->cols, c->rows, c->U, c->ldp, 0, c->A, c->cols, 0, c->W, c->ldp, 0,
+      maus_zgemm_launch_idx(c->st, count, c->cols, c->rows, c->Y, c->ldp, 0, c->A, c->cols, 0, c->W, c->ldp, 0,
                             1.0, 0, 1, 0, false, true, c->d_slots, c->d_slots); }
-    maus_launch_norm_scale(c->st, c->W, c->X, c->ldp, c->d_slots, count, c->cols, c->d_r1, 4, 3);
+    maus_launch_norm_scale(c->st, c->W, c->W, c->ldp, c->d_slots, count, c->cols, c->d_r1, 4, 3);
     HIPCHK(c, hipMemcpyAsync(norms_out, c->d_r1, sizeof(double) * 4 * count, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     return 0;
+}
+
+int maus_svd_commit(maus_ctx* c, const int* slots, int count) {
+    if (!c->X) FAIL(c, "maus_svd_commit: population missing");
+    if (count == 0) return 0;
+    if (upload_slots(c, slots, count)) return -1;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(count), dim3(256), 0, c->st, c->U, c->Y, c->ldp, c->d_slots, c->rows);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(count), dim3(256), 0, c->st, c->X, c->W, c->ldp, c->d_slots, c->cols);
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
+int maus_svd_power_step(maus_ctx* c, const int* slots, int count, double* norms_out) {
+    if (maus_svd_power_propose(c, slots, count, norms_out)) return -1;
+    return maus_svd_commit(c, slots, count);
 }
 
 int maus_herm_match(maus_ctx* c, const int* slots, int count, int32_t* idx_out, double* norm_out) {

@@ -340,7 +340,8 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
                     for (int cc = c + 1; cc < PWL; ++cc) cfms(R[k][cc], l, prow[cc]);
                 }
             }
-            lds_barrier();     // s_piv / s_val / s_pphys are rewritten by the next column
+            // no barrier here: the next column rewrites s_val behind this column's second barrier (everybody has read it)
+            // and s_piv / s_pphys behind its own first barrier (everybody has finished this update)
         }
         PCLK(3);
         // store the factored sub-block (L below the pivots; the pivot rows' own entries are only read back by (b'))
@@ -362,6 +363,140 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
 }
 
 #if MAUS_NBP == 16
+// ---------------------------------------------------------------------------------------
+// Base panel for m <= 1024 (round 3): one workgroup per matrix keeps its WHOLE 16-column slice in registers -- one or two
+// rows of 16 columns per thread -- so the panel is read once and written once (32 column passes; the left-looking kernel
+// above re-reads its finished columns: 40-56 passes) and factored right-looking: per pivot column one search, one
+// exchange of the pivot row through LDS, one rank-1 update of the columns to its right.  Same pivot rule (izamax over
+// logical rows, first index wins), same implicit interchange (register rows and perm entries swap) as the other panels.
+// Every panel of a 1024 x 1024 factorisation (BASELINE configs[1]) and the last quarter of the panels at n = 4096.
+// ---------------------------------------------------------------------------------------
+template <int RPT>
+__global__ void __launch_bounds__(PT)
+lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long strideH, int j0, int m,
+                   int* __restrict__ ipiv_g, int* __restrict__ perm_g, int npad, int* __restrict__ info_g)
+{
+    const int g = blockIdx.x;
+    c128* Hm = Hg + (long)g * strideH + lu_tile_off(npad, j0);                             // tile-major: see lu_panel_ip_kernel
+    c128* Um = Ug + (long)g * strideH + lu_tile_off(npad, j0) + (long)j0 * ld;
+    int* ipiv = ipiv_g + (long)g * npad + j0;
+    int* perm = perm_g + (long)g * npad + j0;                     // perm[r]: physical row of panel-local logical row r
+
+    __shared__ double s_val[PT / 64];
+    __shared__ int s_idx[PT / 64];
+    __shared__ c128 s_row[NBP];          // the pivot row
+    __shared__ c128 s_arow[NBP];         // logical row a (displaced by the interchange)
+    __shared__ int s_phys[2];            // physical rows of the pivot row / of logical row a
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    c128 R[RPT][NBP];
+    int pr[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = tid + k * PT;
+        pr[k] = (r < m) ? perm[r] : 0;
+        if (r < m) {
+            const c128* row = Hm + (long)pr[k] * ld;
+#pragma unroll
+            for (int c = 0; c < NBP; ++c) R[k][c] = row[c];
+        }
+    }
+    int my_info = 0;
+    auto step = [&](auto AC) {
+        constexpr int a = decltype(AC)::value;
+        // ---- pivot search: max |re|+|im| over logical rows >= a, first index wins ----
+        double best = -1.0; int bidx = INT_MAX;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = tid + k * PT;
+            if (r < m && r >= a) {
+                double v = cabs1(R[k][a]);
+                if (v > best) { best = v; bidx = r; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            double ov = __shfl_xor(best, o, 64);
+            int oi = __shfl_xor(bidx, o, 64);
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        }
+        if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
+        lds_barrier();
+        best = s_val[0]; bidx = s_idx[0];
+#pragma unroll
+        for (int q = 1; q < PT / 64; ++q) {
+            double ov = s_val[q]; int oi = s_idx[q];
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        }
+        const int p = (bidx == INT_MAX) ? a : bidx;   // all-NaN column: no interchange (input flagged non-finite)
+        // ---- publish the pivot row and the row it displaces ----
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = tid + k * PT;
+            if (r == p) {
+#pragma unroll
+                for (int c = 0; c < NBP; ++c) s_row[c] = R[k][c];
+                s_phys[0] = pr[k];
+            }
+            if (r == a && p != a) {
+#pragma unroll
+                for (int c = 0; c < NBP; ++c) s_arow[c] = R[k][c];
+                s_phys[1] = pr[k];
+            }
+        }
+        lds_barrier();
+        // ---- the interchange: the owners of logical rows a and p exchange register rows and physical rows ----
+        if (p != a) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = tid + k * PT;
+                if (r == a) {
+#pragma unroll
+                    for (int c = 0; c < NBP; ++c) R[k][c] = s_row[c];
+                    pr[k] = s_phys[0];
+                } else if (r == p) {
+#pragma unroll
+                    for (int c = 0; c < NBP; ++c) R[k][c] = s_arow[c];
+                    pr[k] = s_phys[1];
+                }
+            }
+        }
+        const c128 pv = s_row[a];
+        const bool zero_piv = (pv.x == 0.0 && pv.y == 0.0);
+        if (zero_piv && my_info == 0) my_info = j0 + a + 1;              // LAPACK info (1-based)
+        if (tid == 0) ipiv[a] = j0 + p;
+        if (tid < NBP && tid >= a) Um[(long)a * ld + tid] = s_row[tid];   // row a of U inside the panel
+        const c128 rinv = zero_piv ? cmake(1.0, 0.0) : crecip(pv);
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = tid + k * PT;
+            if (r < m && r > a) {
+                const c128 l = cmul(R[k][a], rinv);
+                R[k][a] = l;
+#pragma unroll
+                for (int c = 0; c < NBP; ++c) if (c > a) cfms(R[k][c], l, s_row[c]);
+            }
+        }
+        // two barriers per column are enough: the next column rewrites s_val behind this column's second barrier
+        // (everybody has read it) and s_row behind its own first barrier (everybody has finished this update)
+    };
+#define RS_STEP(A) step(std::integral_constant<int, A>{})
+    RS_STEP(0); RS_STEP(1); RS_STEP(2); RS_STEP(3); RS_STEP(4); RS_STEP(5); RS_STEP(6); RS_STEP(7);
+    RS_STEP(8); RS_STEP(9); RS_STEP(10); RS_STEP(11); RS_STEP(12); RS_STEP(13); RS_STEP(14); RS_STEP(15);
+#undef RS_STEP
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = tid + k * PT;
+        if (r < m) {
+            c128* row = Hm + (long)pr[k] * ld;
+#pragma unroll
+            for (int c = 0; c < NBP; ++c) row[c] = R[k][c];
+            perm[r] = pr[k];
+        }
+    }
+    if (tid == 0 && my_info != 0 && info_g[g] == 0) info_g[g] = my_info;
+}
+
 // ---------------------------------------------------------------------------------------
 // Base panel spread over W workgroups per matrix (small batches: with one workgroup per matrix a batch of 32 occupies 32
 // of the 256 CUs and the panel phase is bound by one CU's memory pipeline per matrix).  Workgroup w owns the logical rows
@@ -777,8 +912,16 @@ static void lu_panel(const LuWs& w, int j0) {
     // only LU in flight on the device (w.mw_sync set) and all G*W workgroups fit on the chip at once -- the workgroups of a
     // matrix wait for each other.
 #if MAUS_NBP == 16
+    // m <= 1024: the whole slice in the registers of one workgroup (MAUS_PANEL_RS=0: the left-looking kernel, measurement)
+    static const int rs_on = [] { const char* e = getenv("MAUS_PANEL_RS"); return e ? atoi(e) : 1; }();
+    if (rs_on && m <= 2 * PT) {
+        if (m <= PT) hipLaunchKernelGGL((lu_panel_rs_kernel<1>), grid, block, 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, j0, m, w.ipiv, w.perm, w.npad, w.info);
+        else hipLaunchKernelGGL((lu_panel_rs_kernel<2>), grid, block, 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, j0, m, w.ipiv, w.perm, w.npad, w.info);
+        prof(w, KC_PANEL, 1, 8.0 * m * NBP * NBP / 2 * w.G, 16.0 * m * NBP * 2 * w.G);
+        return;
+    }
     static const int mw_on = [] { const char* e = getenv("MAUS_PANEL_MW"); return e ? atoi(e) : 1; }();
-    if (mw_on && w.mw_sync && m >= 1024) {
+    if (mw_on && w.mw_sync && m > 1024) {
         static const int ncu = [] { int v = 0; int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
         auto p2floor = [](int x) { int p = 1; while (2 * p <= x) p *= 2; return p; };
         auto p2ceil = [](int x) { int p = 1; while (p < x) p *= 2; return p; };

@@ -8,9 +8,8 @@
 //     g_i(x) = x^(624*Dj*2^i) mod phi (host, cached; Dj = floor(2N^2/624) - 1 blocks).  A jump is
 //     evaluated as a CONVOLUTION: g(F) s = sum_i g_i F^i s and F^i s is the stream shifted by i words,
 //     so out[j] = XOR_{i : g_i = 1} x[i + j] over the next 19937+624 words -- no 19937-step Horner chain.
-//  2. S workgroups per candidate (each owning a contiguous range of elements, reached by a second lifting
-//     over the sub-stream index) then walk both streams block by block (the 624-word regeneration
-//     has three dependency phases of 227/227/170 words), tempers, converts word pairs to doubles
+//  2. S workgroups per candidate (each owning a contiguous range of elements, reached by a doubling tree
+//     over the sub-stream index) then walk both streams block by block, temper, convert word pairs to doubles
 //     exactly as NumPy's legacy random_sample does ((a>>5)*2^26 + (b>>6)) / 2^53, and writes
 //     H = (A - lambda*delta) + (psi*delta + ((u-.5)*psi)*0.15) with NumPy's rounding order.
 #include "common.h"
@@ -39,8 +38,8 @@ __device__ __forceinline__ uint32_t twist(uint32_t u, uint32_t v) {
 //   227 <= k < 454:  new[k] = od[k+170] ^ tw(od[k-227], od[k-226]) ^ tw(od[k], od[k+1])
 //   454 <= k < 624:  new[k] = od[k-57]  ^ tw(od[k-454], od[k-453]) ^ tw(od[k-227], od[k-226]) ^ tw(od[k], od[k+1])
 // (for k = 623 the "od[k+1]" is new[0] = od[397] ^ tw(od[0], od[1])).  1-4 twists per word instead of one, and a
-// whole block costs ONE barrier instead of three: used where a block walk has nothing else to do between barriers
-// (the 33-block prologue of mt_jump_kernel, the start-up regenerations of the H build).
+// whole block costs ONE barrier instead of three: used where a whole workgroup walks blocks with nothing else to do
+// between barriers (the 33-block prologue of mt_jump_kernel).
 __device__ __forceinline__ uint32_t next_word(const uint32_t* od, int k) {
     if (k < MTD) return od[k + MTM] ^ twist(od[k], od[k + 1]);
     if (k < 2 * MTD) return od[k + 170] ^ twist(od[k - MTD], od[k - MTD + 1]) ^ twist(od[k], od[k + 1]);
@@ -99,155 +98,15 @@ __device__ __forceinline__ uint32_t temper(uint32_t y) {
     return y;
 }
 
-constexpr int GT = 640;          // threads: [0,320) drive the U1 stream, [320,640) the U2 stream
-constexpr int HALF = 320;
-constexpr int KB = 4;            // MT blocks generated per consume batch (even: s_last alternates per block)
-static_assert(KB % 2 == 0, "s_last parity");
-constexpr int RING = 2048;       // doubles per stream kept between producer and consumer (> KB*313 + 313)
-constexpr int PFQ = (KB * 313 + GT - 1) / GT;   // A elements each thread prefetches per batch
-
-// H build with regenerated draws.  grid = (S sub-streams, G candidates): workgroup (b, g) builds the elements
-// [b*E, min((b+1)*E, n*n)) of candidate g from its own pair of generator states (the block-level
-// regeneration is barrier-bound, so the work is spread over G*S workgroups).
-__global__ void __launch_bounds__(GT)
-build_h_mt_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long strideH, c128* __restrict__ Hg,
-                  const c128* __restrict__ shift, const double* __restrict__ psi,
-                  int rhs_mode, const c128* __restrict__ X, long ldx, const int* __restrict__ slots,
-                  const c128* __restrict__ bvec,
-                  const uint32_t* __restrict__ states /* [G][S][2][624] */, const int* __restrict__ extra /* [G][S][2] */,
-                  const int* __restrict__ rpos /* [G][S][2] */, long E, int* __restrict__ flags, int tiled)
-{
-    __shared__ uint32_t blk[2][2][MTN];      // [stream][parity][word]
-    __shared__ double ring[2][RING];
-    __shared__ long s_emitted[2];
-    __shared__ uint32_t s_last[2][2];            // [stream][parity] last word of the block before the current one
-    const int g = blockIdx.y, sb = blockIdx.x, S = gridDim.x, tid = threadIdx.x;
-    const int s = tid / HALF, lt = tid - s * HALF;            // stream id, thread within the stream group
-    const long gi = ((long)g * S + sb) * 2;                   // index of this workgroup's first generator
-    c128* H = Hg + (long)g * strideH;
-    // element (i, j): row-major with leading dimension ldh (GMRES operand) or tile-major (LU workspace, luws.h)
-    auto hidx = [&](int i, int j) -> long { return tiled ? lu_tix(npad, i, j) : (long)i * ldh + j; };
-    const c128 lam = shift[g];
-    const double ps = psi[g];
-    bool bad = false;
-
-    if (sb == 0) {
-        // pad rows / pad columns / augmented block (everything outside the n x n perturbation area)
-        for (long e = tid; e < (long)npad * (ldh - n); e += GT) {          // columns n..ldh of every row
-            const int i = (int)(e / (ldh - n)), j = n + (int)(e - (long)i * (ldh - n));
-            c128 v = cmake(0.0, 0.0);
-            if (j < npad) { if (i == j) v.x = 1.0; }
-            else if (j == npad && i < n) { v = (rhs_mode == 0) ? X[(long)slots[g] * ldx + i] : bvec[i]; bad |= !cfinite(v); }
-            H[hidx(i, j)] = v;
-        }
-        for (long e = tid; e < (long)(npad - n) * n; e += GT) {            // pad rows, columns 0..n
-            const int i = n + (int)(e / n), j = (int)(e - (long)(i - n) * n);
-            H[hidx(i, j)] = cmake(0.0, 0.0);
-        }
-    }
-
-    // bring each stream to its start block
-    {
-        const uint32_t* St = states + (gi + s) * MTN;
-        for (int k = lt; k < MTN; k += HALF) blk[s][0][k] = St[k];
-    }
-    __syncthreads();
-    const int ex0 = extra[gi], ex1 = extra[gi + 1];
-    const int exmax = max(ex0, ex1);
-    for (int it = 0; it < exmax; ++it) {       // both groups step together; a group that is done idles through the barriers
-        const int mine = (s == 0) ? ex0 : ex1;
-        const bool act = it < mine;
-        const uint32_t* od = blk[s][min(it, mine) & 1];
-        uint32_t* nw = blk[s][(min(it, mine) + 1) & 1];
-        if (act) for (int k = lt; k < MTN; k += HALF) nw[k] = next_word(od, k);
-        __syncthreads();
-    }
-    int cur = ((s == 0) ? ex0 : ex1) & 1;            // parity slot holding this stream's current block
-    int wpos = rpos[gi + s];                         // next unread word of the current block (0..623)
-    const long e0 = (long)sb * E;
-    const long total = min((long)n * n, e0 + E);     // this workgroup's element range is [e0, total)
-    long emitted = e0;                               // absolute index of the next double this stream produces
-    long done = e0;
-    // a double = words (t, t+1); a pair may straddle two blocks when the stream starts at an odd position
-    while (done < total) {
-        // A values of the elements this batch will finish, requested before the generation work hides their latency
-        c128 apf[PFQ];
-#pragma unroll
-        for (int q = 0; q < PFQ; ++q) {
-            const long e = done + tid + (long)q * GT;
-            apf[q] = A[min(e, total - 1)];        // clamped index, no select on the value: the load stays in flight
-        }
-        for (int bi = 0; bi < KB; ++bi) {
-            const uint32_t* cb = blk[s][cur];
-            uint32_t* nb = blk[s][cur ^ 1];                               // previous block, about to become the next one
-            // ---- produce: all doubles whose second word lies in the current block ----
-            {
-                const int first = wpos;                                   // -1: the pair started on the previous block's last word
-                const int npairs = (MTN - first) / 2;
-                const uint32_t prev_last = s_last[s][bi & 1];             // (only read when first == -1)
-                for (int q = lt; q < npairs; q += HALF) {
-                    const int t = first + 2 * q;
-                    const uint32_t a = temper(t >= 0 ? cb[t] : prev_last) >> 5, b = temper(cb[t + 1]) >> 6;
-                    const long e = emitted + q;
-                    if (e < total) ring[s][e & (RING - 1)] = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
-                }
-                emitted += npairs;
-                wpos = ((MTN - first) & 1) ? -1 : 0;
-            }
-            // ---- next block of each stream, started in the same barrier interval as the produce pass (its first
-            //      part only reads the current block; the previous block's last word, which a straddling pair
-            //      needs, travels through s_last) ----
-            if (lt == 0) s_last[s][(bi + 1) & 1] = cb[MTN - 1];
-            // the three dependent parts of the block, one LDS-only barrier each.  (Computing every word from the
-            // current block alone -- next_word(), one barrier per block -- was measured too: 59.6 vs 52.9 ms per
-            // 271-matrix step; with cheap barriers the kernel is bound by its integer instructions, and the
-            // one-pass form executes 1.9x the twists.)
-            for (int k = lt; k < MTD; k += HALF) nb[k] = cb[k + MTM] ^ twist(cb[k], cb[k + 1]);
-            lds_barrier();
-            for (int k = MTD + lt; k < 2 * MTD; k += HALF) nb[k] = nb[k - MTD] ^ twist(cb[k], cb[k + 1]);
-            lds_barrier();
-            for (int k = 2 * MTD + lt; k < MTN; k += HALF) nb[k] = nb[k - MTD] ^ twist(cb[k], (k == MTN - 1) ? nb[0] : cb[k + 1]);
-            if (bi == KB - 1 && lt == 0) s_emitted[s] = emitted;
-            lds_barrier();
-            cur ^= 1;
-        }
-        // ---- consume: elements both streams have produced (at most KB*313 <= PFQ*GT of them) ----
-        const long hi = min(min(s_emitted[0], s_emitted[1]), total);
-#pragma unroll
-        for (int q = 0; q < PFQ; ++q) {
-            const long e = done + tid + (long)q * GT;
-            if (e < hi) {
-                const int i = (int)(e / n), j = (int)(e - (long)i * n);
-                const c128 a = apf[q];
-                const double pr = __dmul_rn(__dmul_rn(__dsub_rn(ring[0][e & (RING - 1)], 0.5), ps), 0.15);
-                const double pi = __dmul_rn(__dmul_rn(__dsub_rn(ring[1][e & (RING - 1)], 0.5), ps), 0.15);
-                c128 h;
-                if (j == i) {
-                    h.x = __dadd_rn(__dsub_rn(a.x, lam.x), __dadd_rn(ps, pr));
-                    h.y = __dadd_rn(__dsub_rn(a.y, lam.y), __dadd_rn(0.0, pi));
-                } else {
-                    h.x = __dadd_rn(a.x, pr);
-                    h.y = __dadd_rn(a.y, pi);
-                }
-                bad |= !cfinite(h);
-                H[hidx(i, j)] = h;
-            }
-        }
-        done = hi;
-        lds_barrier();            // ring slots of this batch may be overwritten from here on
-    }
-    if (__any(bad) && (tid & 63) == 0) atomicOr(&flags[g], 1);
-}
-
-
 // ---------------------------------------------------------------------------------------
-// H build with regenerated draws, pipelined over the four waves of a workgroup (round 3; the default).
+// H build with regenerated draws, pipelined over the four waves of a workgroup (round 3).
 // One workgroup per sub-stream: waves 0 / 1 PRODUCE the U1 / U2 stream, waves 2 / 3 CONSUME (temper, convert, build H).
 //   * A producer owns one generator and keeps three blocks of it in LDS.  The next block is written out of place in 10
 //     chunks of 64 words,  nw[k] = (k < 227 ? od[k+397] : nw[k-227]) ^ tw(od[k], od[k+1]):  a chunk only reads words of `nw`
 //     that the same wave wrote at least three chunks earlier, and the LDS operations of one wave complete in order, so the
-//     three dependency phases of a block need no barrier (the 640-thread kernel above spends its time in three barriers
-//     per 624 words, every wave waiting for the slowest).
+//     three dependency phases of a block need no barrier (round 2's kernel -- 320 threads per stream, three barriers per
+//     624 words, every wave waiting for the slowest, a ring of doubles between production and consumption -- took 27 ms
+//     per 181 matrices at n = 4096 where this one takes 15).
 //   * In iteration t the producers write block t+2 while the consumers convert the 312 elements that block t is worth:
 //     element q needs the words rpos + 2q, rpos + 2q + 1 counted from the start of block t, i.e. words of block t or
 //     (past 623) of block t+1 -- both resident, so there is no ring buffer between producer and consumer, no lag
@@ -261,7 +120,7 @@ build_h_mt_kernel(const c128* __restrict__ A, int n, int npad, long ldh, long st
 // Against one wave per sub-stream doing everything (measured: 18.5 ms per 181 matrices at 32 sub-streams, but 44 ms of
 // jump kernels to get 11 584 generator states) this needs a quarter of the generators for the same parallelism.
 // grid = (G candidates, S sub-streams): blockIdx.x = candidate, so that the workgroups resident at any time read the same
-// stretch of A (the 640-thread kernel fetched 0.7 x |A| from HBM per candidate, profiles/r02_pmc_traffic_per_kernel.txt).
+// stretch of A (round 2's kernel fetched 0.7 x |A| from HBM per candidate, profiles/r02_pmc_traffic_per_kernel.txt).
 // ---------------------------------------------------------------------------------------
 constexpr int EPB = MTN / 2;                 // elements (doubles) per block and stream
 constexpr int ECH = (EPB + 63) / 64;         // chunks of 64 elements per block (the last one holds 56)
@@ -427,9 +286,6 @@ void maus_mt_jump(hipStream_t st, uint32_t* states, const int* sel, int nsel, co
 void maus_build_h_mt(hipStream_t st, const c128* A, int n, int npad, long ldh, long strideH, c128* H, int G, int S, long E,
                      const c128* d_shift, const double* d_psi, int rhs_mode, const c128* X, long ldx, const int* d_slots,
                      const c128* bvec, const uint32_t* states, const int* extra, const int* rpos, int* flags, int tiled) {
-    static const int old = [] { const char* e = getenv("MAUS_BUILD_MT_OLD"); return e ? atoi(e) : 0; }();
-    if (old) hipLaunchKernelGGL(build_h_mt_kernel, dim3(S, G), dim3(GT), 0, st, A, n, npad, ldh, strideH, H, d_shift, d_psi, rhs_mode,
-                                X, ldx, d_slots, bvec, states, extra, rpos, E, flags, tiled);
-    else hipLaunchKernelGGL(build_h_mt4_kernel, dim3(G, S), dim3(256), 0, st, A, n, npad, ldh, strideH, H, d_shift, d_psi, rhs_mode,
-                            X, ldx, d_slots, bvec, states, extra, rpos, E, flags, tiled);
+    hipLaunchKernelGGL(build_h_mt4_kernel, dim3(G, S), dim3(256), 0, st, A, n, npad, ldh, strideH, H, d_shift, d_psi, rhs_mode,
+                       X, ldx, d_slots, bvec, states, extra, rpos, E, flags, tiled);
 }

@@ -269,8 +269,9 @@ class DeviceEngine:
             lv = lazy[0]._len_v()
             iv = self.ctx.hist_append(POP_X, slots, lv)
             iu = self.ctx.hist_append(POP_U, slots, lazy[0].M_rows) if svd else None
+            gen = self.ctx.hist_generation() if hasattr(self.ctx, "hist_generation") else 0      # once per step, not per candidate
             for k, c in enumerate(lazy):
-                c._hist_ref = ((iu + k, c.M_rows), (iv + k, lv)) if svd else ((iv + k, lv),)
+                c._hist_ref = (((iu + k, c.M_rows), (iv + k, lv)) if svd else ((iv + k, lv),), gen)
 
     # ---- perturbation mode ---------------------------------------------------------------
     def _pert(self, n: int) -> int:
@@ -380,13 +381,20 @@ class DeviceEngine:
         return f[:, 0], f[:, 1] != 0
 
     def d_svd_power(self, cands):
+        """Speculative power step: norms only, the candidates' vectors stay as they are (d_svd_commit applies it)."""
         mine = self._mine(cands)
         if mine is None:
-            return self.ctx.svd_power_step([c._slot for c in cands])
+            return self.ctx.svd_power_propose([c._slot for c in cands])
         loc = np.zeros((len(mine), 4))
         if mine:
-            loc = self.ctx.svd_power_step([cands[k]._slot for k in mine])
+            loc = self.ctx.svd_power_propose([cands[k]._slot for k in mine])
         return self._exchange(cands, loc)
+
+    def d_svd_commit(self, cands):
+        mine = self._mine(cands)
+        own = cands if mine is None else [cands[k] for k in mine]
+        if own:
+            self.ctx.svd_commit([c._slot for c in own])
 
     def d_herm_match(self, cands):
         mine = self._mine(cands)
@@ -444,7 +452,8 @@ class DeviceEngine:
         self.bind_rhs(b)
         n_vec = max(cands[0].M_rows, cands[0].M_cols)
         # host mirrors double as the pre-step backup wherever a speculative batch may have to be undone
-        need_backup = kind == ProblemType.SVD or (kind != ProblemType.SVD and self._pert(cands[0].N_diag) == PERT_UNIFORM)
+        # (the SVD step needs none: its speculative pass is only committed for the candidates in front of an event)
+        need_backup = kind != ProblemType.SVD and self._pert(cands[0].N_diag) == PERT_UNIFORM
         if self.comm is not None:
             own = self.comm.owners(len(cands))
             self._owner = {id(c): int(own[k]) for k, c in enumerate(cands)}
@@ -552,23 +561,26 @@ class DeviceEngine:
     def _svd(self, cands, A, strat):
         from .solver import SolutionCandidate
         S = SolutionCandidate.State
+        tiny = SIGMA_SIMILARITY_TOL_ABS / 100
         i = 0
         while i < len(cands):
             run = cands[i:]
-            # speculative: the whole run; norms = (||v_in||, sigma1, ||u||, sigma2)
+            # speculative: the whole run; norms = (||v_in||, sigma1, ||u||, sigma2).  Nothing is written to the candidates'
+            # vectors until the commit below, so the candidates behind an event need no restoring
             norms = self.d_svd_power(run)
             # first candidate that takes an exceptional branch
-            ev = None
-            for k in range(len(run)):
-                if norms[k, 0] < 1e-10 or norms[k, 2] < 1e-10 or not np.all(np.isfinite(norms[k])):
-                    ev = k
-                    break
+            bad = (norms[:, 0] < 1e-10) | (norms[:, 2] < 1e-10) | ~np.isfinite(norms).all(axis=1)
+            ev = int(np.argmax(bad)) if bad.any() else None
             good = run if ev is None else run[:ev]
+            self.d_svd_commit(good)
+            ng = len(good)
+            sig = np.where(norms[:ng, 3] > norms[:ng, 1], norms[:ng, 3], norms[:ng, 1])   # max(s1, s2), AMS:234, 241 (finite here)
+            conv = (sig < tiny).tolist()
             for k, c in enumerate(good):
-                s1, s2 = norms[k, 1], norms[k, 3]
-                c.sigma_k = max(np.float64(s1), np.float64(s2))           # AMS:234, 241
-                c._invalidate()
-                if c.sigma_k < SIGMA_SIMILARITY_TOL_ABS / 100:            # AMS:243-247
+                c.sigma_k = sig[k]
+                c._host_valid = False                                     # _invalidate(): the device rows are the new state
+                c._dev_valid = True
+                if conv[k]:                                               # AMS:243-247
                     c.residual_k = strat.get("current_convergence_threshold", 1e-6) * 0.1
                     c.state = S.CONVERGED
                     c.stuck_counter = 0
@@ -582,22 +594,18 @@ class DeviceEngine:
                     if norms[k, 3] < 1e-10:
                         c.right_v_k = np.ones(c.M_cols, dtype=np.complex128) / np.sqrt(c.M_cols)
                         c._push(force=True)
-                else:
-                    c.stuck_counter = max(0, c.stuck_counter - 1)
+                elif c.stuck_counter:
+                    c.stuck_counter -= 1                                  # max(0, stuck - 1)
             if ev is None:
                 break
             self._svd_exception(run[ev], norms[ev])
-            # the speculative pass also touched the candidates behind the event; their inputs were
-            # their own vectors only (no RNG dependence), so redo them from restored state
-            for c in run[ev + 1:]:
-                c._restore_device()
             i += ev + 1
 
     def _svd_exception(self, c, nrm):
         """Sequential semantics for the collapse / failure branches (AMS:229-232, 236-239, 249-255)."""
         from .solver import SolutionCandidate
         S = SolutionCandidate.State
-        c._restore_device()
+        # (the device rows of c are still its pre-step vectors: the speculative pass was not committed for it)
         if nrm[0] < 1e-10:                                   # right vector collapsed (AMS:229-232)
             v = (np.random.rand(c.M_cols) + 1j * np.random.rand(c.M_cols))
             v /= np.linalg.norm(v)
@@ -625,6 +633,7 @@ class DeviceEngine:
         else:
             # non-finite norms: redo this candidate alone and accept what comes out
             norms = self.d_svd_power([c])
+            self.d_svd_commit([c])
             c.sigma_k = max(np.float64(norms[0, 1]), np.float64(norms[0, 3]))
             c._invalidate()
             c.stuck_counter = max(0, c.stuck_counter - 1)
@@ -904,52 +913,72 @@ class DeviceEngine:
 
     # ---- residual, histories, alpha/state adaptation, convergence (AMS:295-331) -------------
     def _finish(self, cands, A, b, strat):
+        """Residuals (AMS:295-301), histories (AMS:303-304), alpha / state adaptation (AMS:306-316) and the convergence test
+        (AMS:318-331) of every stepped candidate.  The decisions are taken on arrays over the whole list and applied in one
+        pass (at 6144 candidates -- BASELINE configs[4] -- per-candidate NumPy scalar arithmetic was 40 ms per loop body,
+        more than the body's kernels)."""
         from .solver import ProblemType, SolutionCandidate
         S = SolutionCandidate.State
         kind = cands[0].problem_type
+        n = len(cands)
+        pos = {id(c): k for k, c in enumerate(cands)}
+        resv = np.empty(n, dtype=np.float64)
+        okv = np.empty(n, dtype=bool)
         # residual against the construction-time matrix of each candidate (SURVEY F9)
         groups = {}
         for c in cands:
             groups.setdefault(id(c.problem_matrix), []).append(c)
-        finite = {}
         for _, grp in groups.items():
             self.bind_matrix(grp[0].problem_matrix)
+            ix = np.fromiter((pos[id(c)] for c in grp), dtype=np.int64, count=len(grp))
             if kind == ProblemType.EIGENVALUE:
                 lam = np.array([complex(c.lambda_k) for c in grp], dtype=np.complex128)
                 res, fin = self.d_residual(KIND_EIG, grp, lam)
+                fin = np.asarray(fin, dtype=bool) & np.isfinite(lam)
             elif kind == ProblemType.SOLVE_LINEAR_SYSTEM:
                 res, fin = self.d_residual(KIND_LINEAR, grp, None)
+                fin = np.asarray(fin, dtype=bool)
             else:
                 sig = np.array([complex(c.sigma_k) for c in grp], dtype=np.complex128)
                 res, fin = self.d_residual(KIND_SVD, grp, sig)
+                fin = np.asarray(fin, dtype=bool) & np.isfinite(sig)
+            resv[ix] = res
+            okv[ix] = fin
             for k, c in enumerate(grp):
                 c.residual_k = res[k]
-                finite[id(c)] = bool(fin[k])
         self.bind_matrix(A)
         thr = strat.get("current_convergence_threshold", CONVERGENCE_RESIDUAL_TOL)
         self._stage_history(cands)
-        for c in cands:
+        prev = np.array([c.prev_residual for c in cands], dtype=np.float64)
+        alpha = np.array([c.alpha_local_step for c in cands], dtype=np.float64)
+        with np.errstate(invalid="ignore", over="ignore"):
+            live = prev > 1e-10                                                  # AMS:306
+            m1 = live & (resv < prev * 0.9)                                      # AMS:307 -> REFINING
+            m2 = live & ~m1 & (resv > prev * 1.5) & (prev > 1e-5)                # AMS:310 -> STUCK
+            m3 = live & ~m1 & ~m2                                                # AMS:313 -> EXPLORING
+            new_alpha = np.where(m1, np.minimum(alpha * 1.1, 1.0),
+                                 np.where(m2, np.maximum(alpha * 0.5, 1e-6), np.maximum(alpha * 0.95, 1e-6)))
+            conv = (resv < thr) & okv                                            # AMS:318-331
+        code = (m1 * 1 + m2 * 2 + m3 * 3).tolist()
+        new_alpha = new_alpha.tolist()
+        conv = conv.tolist()
+        CONV, STUCK, RETIRED = S.CONVERGED, S.STUCK, S.RETIRED
+        for k, c in enumerate(cands):
             c._record_history()                                          # AMS:303-304
-            if c.prev_residual > 1e-10:                                  # AMS:306-316
-                if c.residual_k < c.prev_residual * 0.9:
-                    c.alpha_local_step = min(c.alpha_local_step * 1.1, 1.0)
-                    if c.state != S.CONVERGED:
+            cd = code[k]
+            if cd:
+                c.alpha_local_step = new_alpha[k]
+                st = c.state
+                if cd == 1:
+                    if st is not CONV:
                         c.state = S.REFINING
-                elif c.residual_k > c.prev_residual * 1.5 and c.prev_residual > 1e-5:
-                    c.alpha_local_step = max(c.alpha_local_step * 0.5, 1e-6)
-                    if c.state != S.CONVERGED:
-                        c.state = S.STUCK
-                else:
-                    c.alpha_local_step = max(c.alpha_local_step * 0.95, 1e-6)
-                    if c.state not in (S.CONVERGED, S.STUCK, S.RETIRED):
-                        c.state = S.EXPLORING
-            ok = finite[id(c)]
-            if kind == ProblemType.EIGENVALUE:
-                ok = ok and bool(np.isfinite(c.lambda_k))
-            elif kind == ProblemType.SVD:
-                ok = ok and bool(np.isfinite(c.sigma_k))
-            if c.residual_k < thr and ok:                                # AMS:329-331
-                c.state = S.CONVERGED
+                elif cd == 2:
+                    if st is not CONV:
+                        c.state = STUCK
+                elif st is not CONV and st is not STUCK and st is not RETIRED:
+                    c.state = S.EXPLORING
+            if conv[k]:
+                c.state = CONV
                 c.w_k = 1.0
                 c.stuck_counter = 0
                 c.alpha_local_step = 0.0

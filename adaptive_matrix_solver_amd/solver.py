@@ -18,6 +18,7 @@ Documented deviations:
 """
 from __future__ import annotations
 
+import math
 import random
 from enum import Enum
 
@@ -184,9 +185,11 @@ class _HistRef:
     of whoever appended next."""
     __slots__ = ("ctx", "scalar", "rows", "gen")
 
-    def __init__(self, ctx, scalar, rows):
+    def __init__(self, ctx, scalar, rows, gen=None):
         self.ctx, self.scalar, self.rows = ctx, scalar, rows          # rows: ((history index, length), ...)
-        self.gen = ctx.hist_generation() if hasattr(ctx, "hist_generation") else 0
+        if gen is None:
+            gen = ctx.hist_generation() if hasattr(ctx, "hist_generation") else 0
+        self.gen = gen
 
     def resolve(self):
         if hasattr(self.ctx, "hist_generation") and self.ctx.hist_generation() != self.gen:
@@ -383,8 +386,10 @@ class SolutionCandidate:
         problems, a device-to-device append to the history store (self._hist_ref) above n = 512."""
         if self._record:
             if self._hist_ref is not None:
-                scalar = {ProblemType.EIGENVALUE: self.lambda_k, ProblemType.SVD: self.sigma_k}.get(self.problem_type)
-                self.param_history.append(_HistRef(self._engine.ctx, scalar, self._hist_ref))
+                pt = self.problem_type
+                scalar = self.lambda_k if pt == ProblemType.EIGENVALUE else (self.sigma_k if pt == ProblemType.SVD else None)
+                rows, gen = self._hist_ref                        # staged by the engine: store rows + the store's generation
+                self.param_history.append(_HistRef(self._engine.ctx, scalar, rows, gen))
                 self._hist_ref = None
             else:
                 self.param_history.append(self.get_current_solution_params())
@@ -614,6 +619,7 @@ class MAUS_Solver:
         self.converged_solutions = []
         current_sigma_magnitudes = []
         thr = self.strat_params["current_convergence_threshold"]
+        max_s = None
         for c in self.candidates:
             if c.state == C.CONVERGED:
                 num_converged_all_types += 1
@@ -641,8 +647,9 @@ class MAUS_Solver:
                             < self.strat_params["convergence_tolerance"] * 100):
                         is_distinct = False
                 elif self.problem_type == ProblemType.SVD:
-                    max_s = max((cand.sigma_k.real for cand in self.candidates
-                                 if cand.sigma_k is not None and cand.sigma_k.real > 0), default=1.0)
+                    if max_s is None:                  # AMS:444: the same value for every converged candidate of this pass
+                        max_s = max((cand.sigma_k.real for cand in self.candidates
+                                     if cand.sigma_k is not None and cand.sigma_k.real > 0), default=1.0)
                     if current_tuple[0].real / max_s < GLOBAL_SIGMA_SIMILARITY_TOL_REL:
                         is_distinct = False
                     if is_distinct and gram is not None:
@@ -669,7 +676,7 @@ class MAUS_Solver:
                         acc_pos.append(gpos[id(c)])
                         acc_key.append(current_tuple[0])
             if c.state not in (C.CONVERGED, C.RETIRED):
-                sum_residuals += c.residual_k if np.isfinite(c.residual_k) else (thr * 100)
+                sum_residuals += c.residual_k if math.isfinite(c.residual_k) else (thr * 100)
                 sum_stuck_counters += c.stuck_counter
         non_conv_retired_count = max(1, total_active_candidates - num_converged_all_types)
         self.avg_residual = sum_residuals / non_conv_retired_count
@@ -726,8 +733,12 @@ class MAUS_Solver:
     def _manage_candidates(self, iteration):
         C = SolutionCandidate.State
         survivors = []
-        sorted_candidates = sorted(self.candidates,
-                                   key=lambda x: (-x.w_k, x.residual_k if np.isfinite(x.residual_k) else float("inf")))
+        # sorted(key=lambda x: (-x.w_k, x.residual_k if isfinite else inf)), AMS:506, with the keys built on arrays (the
+        # per-candidate np.isfinite of the lambda was 9 ms per loop body at 6144 candidates); same tuples, same stable sort
+        res_key = np.array([c.residual_k for c in self.candidates], dtype=np.float64)
+        res_key = np.where(np.isfinite(res_key), res_key, np.inf).tolist()
+        keys = [(-c.w_k, r) for c, r in zip(self.candidates, res_key)]
+        sorted_candidates = [self.candidates[k] for k in sorted(range(len(keys)), key=keys.__getitem__)]
         tol = self.strat_params["convergence_tolerance"]
         gpos, gram = self._converged_gram()
         sur_pos, sur_key = [], []                          # Gram positions / lambda (sigma) of the converged survivors

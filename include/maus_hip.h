@@ -172,6 +172,13 @@ int maus_residual(maus_ctx* ctx, int kind, const int* slots, int count, const do
  * sigma2 = ||s||; v = s / (sigma2 > 1e-10 ? sigma2 : 1).
  * Outputs per candidate: norms[4] = {||v_in||, sigma1, ||u||, sigma2}. */
 int maus_svd_power_step(maus_ctx* ctx, const int* slots, int count, double* norms_out);
+/* The same step in two halves, for callers that run it speculatively over a whole population (the reference steps the
+ * candidates one after the other, AMS:574-576, and a collapse -- AMS:229-232, 236-239 -- draws random numbers that the
+ * candidates behind it must not have passed): propose computes the norms and leaves the candidates' vectors alone (the
+ * proposed u in population array 3, the proposed v in array 2), commit makes the proposal the state of the listed
+ * candidates.  maus_svd_power_step = propose + commit of the same list. */
+int maus_svd_power_propose(maus_ctx* ctx, const int* slots, int count, double* norms_out);
+int maus_svd_commit(maus_ctx* ctx, const int* slots, int count);
 
 /* Hermitian shortcut                                               AMS:165-175:
  * given the eigenvector matrix V (n x n, columns = eigenvectors, uploaded once

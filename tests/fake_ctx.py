@@ -147,7 +147,7 @@ class FakeContext:
                 fin[k] = np.all(np.isfinite(v)) and np.all(np.isfinite(u))
         return res, fin
 
-    def svd_power_step(self, slots):
+    def svd_power_propose(self, slots):
         out = np.empty((len(slots), 4))
         for k, s in enumerate(slots):
             v = self.pop[0][s, : self.cols]
@@ -160,8 +160,18 @@ class FakeContext:
             w = self.A.conj().T @ u
             s2 = np.linalg.norm(w)
             out[k, 3] = s2
-            self.pop[1][s, : self.rows] = u
-            self.pop[0][s, : self.cols] = w / (s2 if s2 > 1e-10 else 1.0)
+            self.pop[3][s, : self.rows] = u                                   # proposal: u in POP_Y, v in POP_W
+            self.pop[2][s, : self.cols] = w / (s2 if s2 > 1e-10 else 1.0)
+        return out
+
+    def svd_commit(self, slots):
+        for s in slots:
+            self.pop[1][s, : self.rows] = self.pop[3][s, : self.rows]
+            self.pop[0][s, : self.cols] = self.pop[2][s, : self.cols]
+
+    def svd_power_step(self, slots):
+        out = self.svd_power_propose(slots)
+        self.svd_commit(slots)
         return out
 
     def gram(self, which, slots, length):

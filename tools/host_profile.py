@@ -1,18 +1,31 @@
-"""cProfile of the host side of one loop body at the metric configuration (tools, not product)."""
-import cProfile, pstats, os, sys, random, io
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+"""cProfile of loop bodies of a BASELINE configuration on the device (tools, not product): where the HOST time of a loop
+body goes once the kernels are fast.
+
+    python tools/host_profile.py c2|c5 [loop bodies]
+"""
+import cProfile, pstats, os, sys, random, io, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import numpy as np, scenarios
 from adaptive_matrix_solver_amd.solver import MAUS_Solver, ProblemType, SolutionCandidate
-n, P = int(os.environ.get("N", 4096)), int(os.environ.get("P", 256))
-A = scenarios.ginibre(n, n)
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c5"
+bodies = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+if cfg == "c5":
+    A, PT, P = scenarios.prescribed_svd(2048, 2048, 2048, -8.0), ProblemType.SVD, 512
+elif cfg == "c2":
+    A, PT, P = scenarios.ginibre(1024, 1024), ProblemType.EIGENVALUE, 256
+else:
+    raise SystemExit("c2 or c5")
 np.random.seed(1234); random.seed(1234); SolutionCandidate._candidate_id_counter = 0
-s = MAUS_Solver(A, ProblemType.EIGENVALUE, initial_num_candidates=P, quiet=True, record_history=False)
-W = int(os.environ.get("WARM", 1))
-for it in range(1, W + 1):
-    s.loop_body(it)
-pr = cProfile.Profile(); pr.enable()
-s.loop_body(W + 1); s.loop_body(W + 2)
-pr.disable()
-out = io.StringIO(); pstats.Stats(pr, stream=out).sort_stats("cumulative").print_stats(28)
-print("\n".join(l[:150] for l in out.getvalue().splitlines()[:60]))
+s = MAUS_Solver(A, PT, initial_num_candidates=P, quiet=True)
+s.loop_body(1)
+s.engine.ctx.sync()
+pr = cProfile.Profile(); t0 = time.perf_counter(); pr.enable()
+act = 0
+for it in range(bodies):
+    act += s.loop_body(2 + it)
+s.engine.ctx.sync()
+pr.disable(); el = time.perf_counter() - t0
+print(f"{cfg}: {act} candidate steps in {bodies} loop bodies, {el * 1e3:.1f} ms, {el / act * 1e6:.1f} us per candidate step")
+out = io.StringIO(); pstats.Stats(pr, stream=out).sort_stats("tottime").print_stats(32)
+print("\n".join(l[:170] for l in out.getvalue().splitlines()[:48]))

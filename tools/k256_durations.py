@@ -9,11 +9,13 @@ can be checked against the profiler's own timestamps.
 """
 import csv
 import glob
+import re
 import sys
 
+LU_ZGEMM = re.compile(r"zgemm(3m_dma)?_kernel<[^>]*, true>")
 trace = [tuple(int(x) for x in line.split()) for line in open(sys.argv[1]) if line.strip()]
 for f in glob.glob(sys.argv[2] + "/**/*kernel_trace.csv", recursive=True):
-    rows = [r for r in csv.DictReader(open(f)) if ("zgemm_kernel" in r["Kernel_Name"] or "zgemm3m_dma_kernel" in r["Kernel_Name"]) and "zgemm_kernel<64, 64" not in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if LU_ZGEMM.search(r["Kernel_Name"])]      # TILED = true: the LU's instantiations
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     if len(rows) != len(trace):
         print(f"{f}: {len(rows)} LU zgemm dispatches vs {len(trace)} trace lines")

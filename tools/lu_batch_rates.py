@@ -1,4 +1,4 @@
-"""ms per solve of one maus_shifted_lu_solve call (n = 4096, device-regenerated perturbation: the bench's mode) as a function
+"""ms per solve of one maus_shifted_lu_solve call (n = 4096 or LU_N, device-regenerated perturbation: the bench's mode) as a function
 of the batch size -- the per-rank workload of a population sharded over N GPUs is pop/N solves per step.
 
     python tools/lu_batch_rates.py [G ...]        (environment switches of the library apply: MAUS_PANEL_MW, MAUS_LU_STREAMS)
@@ -16,7 +16,7 @@ import scenarios  # noqa: E402
 from adaptive_matrix_solver_amd import Context  # noqa: E402
 from adaptive_matrix_solver_amd._cabi import PERT_MT19937  # noqa: E402
 
-n = 4096
+n = int(os.environ.get("LU_N", 4096))
 sizes = [int(a) for a in sys.argv[1:]] or [8, 16, 32, 48, 64, 96, 128, 192, 256, 331]
 A = scenarios.ginibre(n, n)
 ctx = Context(0)

@@ -11,12 +11,14 @@ the LU zgemm instantiations appear in the counter file in the same order.  Outpu
 stdout and gpurun_out/zgemm_pmc_traffic.json for the K>=256 launches (the roofline kernel of bench.py).
 """
 import collections
+import re
 import csv
 import glob
 import json
 import os
 import sys
 
+LU_ZGEMM = re.compile(r"zgemm(3m_dma)?_kernel<[^>]*, true>")
 trace_path, dirs = sys.argv[1], sys.argv[2:]
 trace = [tuple(int(x) for x in line.split()) for line in open(trace_path) if line.strip()]
 
@@ -34,10 +36,9 @@ for d in dirs:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         rows = list(csv.DictReader(open(f)))
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-        # LU trailing-update launches = zgemm dispatches in plain layout; the population products (BLAY=1 /
-        # conjugated) are launched outside the LU and are not in the trace: they use the 64x64 4M kernel with
-        # a row gather, which the LU never does, so "zgemm_kernel<64, 64" identifies them
-        lu_rows = [r for r in rows if ("zgemm_kernel" in r["Kernel_Name"] or "zgemm3m_dma_kernel" in r["Kernel_Name"]) and "zgemm_kernel<64, 64" not in r["Kernel_Name"]]
+        # LU trailing-update launches = the zgemm instantiations on the tile-major workspace (last template argument
+        # TILED = true); the population products are launched outside the LU and are not in the trace
+        lu_rows = [r for r in rows if LU_ZGEMM.search(r["Kernel_Name"])]
         per_counter = collections.defaultdict(list)
         for r in lu_rows:
             per_counter[r["Counter_Name"]].append(r)
