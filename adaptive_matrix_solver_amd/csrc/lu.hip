@@ -370,9 +370,12 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
 // exchange of the pivot row through LDS, one rank-1 update of the columns to its right.  Same pivot rule (izamax over
 // logical rows, first index wins), same implicit interchange (register rows and perm entries swap) as the other panels.
 // Every panel of a 1024 x 1024 factorisation (BASELINE configs[1]) and the last quarter of the panels at n = 4096.
+// NT threads own RPT x NT rows: the workgroup shrinks with the panel (128 / 256 / 512 threads for m <= 256 / 512 / 1024), so
+// that several matrices share a CU -- a 512-thread workgroup at 177 VGPRs has a CU to itself, and a batch of more matrices
+// than CUs then runs its 16 latency-bound pivot steps in two rounds.
 // ---------------------------------------------------------------------------------------
-template <int RPT>
-__global__ void __launch_bounds__(PT)
+template <int RPT, int NT>
+__global__ void __launch_bounds__(NT)
 lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long strideH, int j0, int m,
                    int* __restrict__ ipiv_g, int* __restrict__ perm_g, int npad, int* __restrict__ info_g)
 {
@@ -382,8 +385,8 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
     int* ipiv = ipiv_g + (long)g * npad + j0;
     int* perm = perm_g + (long)g * npad + j0;                     // perm[r]: physical row of panel-local logical row r
 
-    __shared__ double s_val[PT / 64];
-    __shared__ int s_idx[PT / 64];
+    __shared__ double s_val[NT / 64];
+    __shared__ int s_idx[NT / 64];
     __shared__ c128 s_row[NBP];          // the pivot row
     __shared__ c128 s_arow[NBP];         // logical row a (displaced by the interchange)
     __shared__ int s_phys[2];            // physical rows of the pivot row / of logical row a
@@ -393,7 +396,7 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
     int pr[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const int r = tid + k * PT;
+        const int r = tid + k * NT;
         pr[k] = (r < m) ? perm[r] : 0;
         if (r < m) {
             const c128* row = Hm + (long)pr[k] * ld;
@@ -408,7 +411,7 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         double best = -1.0; int bidx = INT_MAX;
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const int r = tid + k * PT;
+            const int r = tid + k * NT;
             if (r < m && r >= a) {
                 double v = cabs1(R[k][a]);
                 if (v > best) { best = v; bidx = r; }
@@ -424,7 +427,7 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         lds_barrier();
         best = s_val[0]; bidx = s_idx[0];
 #pragma unroll
-        for (int q = 1; q < PT / 64; ++q) {
+        for (int q = 1; q < NT / 64; ++q) {
             double ov = s_val[q]; int oi = s_idx[q];
             if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
         }
@@ -432,7 +435,7 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         // ---- publish the pivot row and the row it displaces ----
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const int r = tid + k * PT;
+            const int r = tid + k * NT;
             if (r == p) {
 #pragma unroll
                 for (int c = 0; c < NBP; ++c) s_row[c] = R[k][c];
@@ -449,7 +452,7 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         if (p != a) {
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
-                const int r = tid + k * PT;
+                const int r = tid + k * NT;
                 if (r == a) {
 #pragma unroll
                     for (int c = 0; c < NBP; ++c) R[k][c] = s_row[c];
@@ -469,7 +472,7 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         const c128 rinv = zero_piv ? cmake(1.0, 0.0) : crecip(pv);
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const int r = tid + k * PT;
+            const int r = tid + k * NT;
             if (r < m && r > a) {
                 const c128 l = cmul(R[k][a], rinv);
                 R[k][a] = l;
@@ -486,7 +489,7 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
 #undef RS_STEP
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const int r = tid + k * PT;
+        const int r = tid + k * NT;
         if (r < m) {
             c128* row = Hm + (long)pr[k] * ld;
 #pragma unroll
@@ -915,8 +918,9 @@ static void lu_panel(const LuWs& w, int j0) {
     // m <= 1024: the whole slice in the registers of one workgroup (MAUS_PANEL_RS=0: the left-looking kernel, measurement)
     static const int rs_on = [] { const char* e = getenv("MAUS_PANEL_RS"); return e ? atoi(e) : 1; }();
     if (rs_on && m <= 2 * PT) {
-        if (m <= PT) hipLaunchKernelGGL((lu_panel_rs_kernel<1>), grid, block, 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, j0, m, w.ipiv, w.perm, w.npad, w.info);
-        else hipLaunchKernelGGL((lu_panel_rs_kernel<2>), grid, block, 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, j0, m, w.ipiv, w.perm, w.npad, w.info);
+#define PANEL_RS(NT) hipLaunchKernelGGL((lu_panel_rs_kernel<2, NT>), grid, dim3(NT), 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, j0, m, w.ipiv, w.perm, w.npad, w.info)
+        if (m <= 256) PANEL_RS(128); else if (m <= 512) PANEL_RS(256); else PANEL_RS(512);
+#undef PANEL_RS
         prof(w, KC_PANEL, 1, 8.0 * m * NBP * NBP / 2 * w.G, 16.0 * m * NBP * 2 * w.G);
         return;
     }
