@@ -174,6 +174,8 @@ __device__ unsigned long long g_panel_clk[16];
 // per panel ~45 us (32 solves) to ~100 us (181 solves) in the left-looking loads, ~38 us in the 16 column steps (2.4 us
 // each, instruction-bound: ~800 instructions per step and wave at 4 rows per thread), ~20 us store + barrier, ~9 us (b').
 // One workgroup per matrix draws 20-30 GB/s -- a CU's share of the chip's bandwidth -- whatever the access pattern.
+// Round 3: requesting the next sub-block's raw columns right behind the stores (they do not depend on them) so that they
+// arrive while the barrier waits for the stores to drain: 35.3 vs 32.1 ms per 181-solve sweep, slower, not adopted.
 // Measured and rejected in round 2 (each bit-identical to this kernel, none faster at 32 or 181 solves per call):
 // a column-major scratch copy of the panel (coalesced sub-block loads, but the two transpositions cost what they save:
 // 51.5 vs 53.6 ms per 181-solve sweep, 34.2 vs 30.0 at 32); 1024 threads per workgroup (69 vs 54 ms); one barrier per
@@ -405,6 +407,10 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         }
     }
     int my_info = 0;
+#ifdef MAUS_PANEL_CLOCK
+    unsigned long long tclk = wall_clock64();
+#endif
+    PCLK_SYNC(0);
     auto step = [&](auto AC) {
         constexpr int a = decltype(AC)::value;
         // ---- pivot search: max |re|+|im| over logical rows >= a, first index wins ----
@@ -425,6 +431,7 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         }
         if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
         lds_barrier();
+        PCLK(5);
         best = s_val[0]; bidx = s_idx[0];
 #pragma unroll
         for (int q = 1; q < NT / 64; ++q) {
@@ -448,6 +455,7 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
             }
         }
         lds_barrier();
+        PCLK(6);
         // ---- the interchange: the owners of logical rows a and p exchange register rows and physical rows ----
         if (p != a) {
 #pragma unroll
@@ -480,6 +488,7 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
                 for (int c = 0; c < NBP; ++c) if (c > a) cfms(R[k][c], l, s_row[c]);
             }
         }
+        PCLK(7);
         // two barriers per column are enough: the next column rewrites s_val behind this column's second barrier
         // (everybody has read it) and s_row behind its own first barrier (everybody has finished this update)
     };
@@ -498,6 +507,7 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         }
     }
     if (tid == 0 && my_info != 0 && info_g[g] == 0) info_g[g] = my_info;
+    PCLK_SYNC(4);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ import scenarios  # noqa: E402
 from adaptive_matrix_solver_amd import Context, _cabi  # noqa: E402
 from adaptive_matrix_solver_amd._cabi import PERT_MT19937  # noqa: E402
 
-n = 4096
+n = int(os.environ.get("LU_N", 4096))
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 A = scenarios.ginibre(n, n)
 ctx = Context(0)
@@ -36,7 +36,7 @@ out = (ctypes.c_ulonglong * 16)()
 lib.maus_debug_panel_clocks(out, 1)
 ctx.shifted_lu_solve(sl, lam, psi, 0, PERT_MT19937, desc)
 lib.maus_debug_panel_clocks(out, 1)
-names = ["prologue (perm load)", "(b') pivot-row block + solve", "(c') load + left-looking update", "column loop", "store + barrier", "-", "-", "-",
+names = ["prologue (perm load)", "(b') pivot-row block + solve", "(c') load + left-looking update", "column loop", "store + barrier", "rs: search + reduce + barrier", "rs: pick + publish + barrier", "rs: interchange + update",
          "mw: load panel slice", "mw: scan, reduce, stage candidate", "mw: publish + drain", "mw: arrive + wait", "mw: read candidates", "mw: pick winner",
          "mw: interchange + update", "mw: store slice"]
 tot = sum(out)
@@ -44,5 +44,5 @@ print('(mw rows: summed over the W workgroups of a matrix)')
 print(f"G={G}: per matrix and factorisation (256 panels), ms of thread 0's wall clock; total {tot * 1e-5 / G:.2f} ms")
 for nm, v in zip(names, out):
     if v:
-        print(f"  {nm:34s} {v * 1e-5 / G:8.3f} ms  ({100.0 * v / tot:4.1f} %)   {v * 1e-2 / G / 256:7.2f} us per panel")
+        print(f"  {nm:34s} {v * 1e-5 / G:8.3f} ms  ({100.0 * v / tot:4.1f} %)   {v * 1e-2 / G / (n // 16):7.2f} us per panel")
 ctx.close()
