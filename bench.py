@@ -36,8 +36,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (AMD spec)
 HBM_PEAK_GBS = 8000.0
-PMC_ZGEMM = "r02_zgemm_pmc_traffic.json"
-PMC_KERNELS = "r02_pmc_traffic_per_kernel.json"
+PMC_ZGEMM = "r03_zgemm_pmc_traffic.json"
+PMC_KERNELS = "r03_pmc_traffic_per_kernel.json"
+PMC_MFMA = "r03_pmc_mfma_lds_per_kernel.json"
 
 
 def cpu_baseline(A, n, budget_s=25.0):
@@ -86,6 +87,8 @@ def cpu_baseline(A, n, budget_s=25.0):
     np.random.set_state(st_np); random.setstate(st_py)
     return {"value": steps / el, "unit": "candidate-steps/s", "cores": int(threads), "kind": "port",
             "cpu_model": cpu_model, "blas": blas, "numpy": np.__version__, "scipy": scipy.__version__,
+            "note": "kind 'port': the NumPy/SciPy oracle (a restatement of the reference checked bit for bit against fixtures captured "
+                    "from it), not the reference file itself, which never leaves the build container; a reported baseline, not credit",
             "sample": f"{steps} whole candidate steps ({ncand} candidates x {steps // ncand} iterations) of the NumPy/SciPy oracle at n={n}, "
                       f"{el:.1f} s, BLAS threads={threads}, host cpus={os.cpu_count()}"}
 
@@ -305,6 +308,9 @@ def main():
                          "c3 = 4096x4096 linear system / 512 candidates, GMRES + Jacobi; c4 = 8192x8192 Hermitian eig (the "
                          "shortcut; --pop defaults to one GPU's share of 1024, 128); c5 = 2048x2048 SVD cond 1e8 / 512 candidates")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-history", action="store_true",
+                    help="record_history=False: keep only residual_history (the reference appends every iterate to param_history, "
+                         "AMS:303; the default here does too, into the device-backed store)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the untimed single-stream kernel-timing pass")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the pop = 32/64/128 side runs (N=1 only)")
     ap.add_argument("--kernel-events", choices=["sampled", "all", "off"], default="sampled",
@@ -370,7 +376,7 @@ def main():
     def build(pop, engine=None, diag=None):
         np.random.seed(1234); random.seed(1234); SolutionCandidate._candidate_id_counter = 0
         return MAUS_Solver(A, ProblemType.EIGENVALUE, initial_num_candidates=pop, global_convergence_tol=1e-8,
-                           device=device, pert_mode="auto", comm=comm, quiet=True, record_history=False,
+                           device=device, pert_mode="auto", comm=comm, quiet=True, record_history=not args.no_history,
                            engine=engine, diag_info=diag)
 
     t_build = time.perf_counter()
@@ -508,11 +514,11 @@ def main():
         per_launch_ms = g["ms"] / max(1, g["launches"])
         # HBM bytes per K>=256 zgemm launch from the committed PMC passes (rocprofv3 --pmc cannot be combined with
         # the timed run; profiles/<PMC_ZGEMM> holds the recipe).  Those passes ran the step as ONE chunk on one
-        # stream; the timed region launches half-size sub-batches, so the measured bytes are scaled by the ratio of
+        # stream; the timed loop bodies run other batch sizes, so the measured bytes are scaled by the ratio of
         # algorithmic bytes per launch (the traffic / algorithmic ratio is what carries over).
         traffic = None
         traffic_note = None
-        for name in (PMC_ZGEMM, "r01_zgemm_pmc_traffic.json"):
+        for name in (PMC_ZGEMM, "r02_zgemm_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pm = json.load(f)
@@ -543,6 +549,19 @@ def main():
                                              "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 3)}
         except Exception:
             hbm_kernels = None
+        pmc_mfma = None
+        try:
+            with open(os.path.join(ROOT, "profiles", PMC_MFMA)) as f:
+                pm = json.load(f)["zgemm3m_dma_kernel<2, 3, 2, 2, true>"]
+            pmc_mfma = {"kernel": "zgemm3m_dma_kernel<2, 3, 2, 2, true> (64x64 tiles: the K = 512 outer updates with M, N >= 1536)",
+                        "MfmaUtil": round(pm["mfma_util"], 4), "effective_clock_GHz": round(pm["effective_clock_GHz"], 3),
+                        "mfma_tflops_executed": round(pm["mfma_tflops_executed"], 2),
+                        "mfma_peak_tflops_at_effective_clock": round(pm["mfma_peak_tflops_at_effective_clock"], 2),
+                        "lds_bank_conflict_per_idx_active": pm.get("lds_bank_conflict_per_idx_active"),
+                        "wave_wait_any_share": round(pm["wait_any_share"], 3), "wave_wait_inst_share": round(pm["wait_inst_any_share"], 3),
+                        "source": "profiles/" + PMC_MFMA + " (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs); 256 solves, profiled run)"}
+        except Exception:
+            pmc_mfma = None
         ms_norm = [r["ms"] / max(1, r["active"]) for r in per_step]
         out = {
             "metric": "candidate-steps/sec, n=4096 dense eig pop=256, 1/2/4/8 GPUs vs CPU ref",
@@ -577,6 +596,8 @@ def main():
                          "flops_per_launch_algorithmic": g["flops"] / max(1, g["launches"]),
                          "kernel_time_share": ((g["ms"] / tot_ms) if tot_ms > 0 else None) if args.kernel_events == "all" else None,
                          "measured_mfma_f64_issue_rate_tflops": 77.9,
+                         # hardware counters of the K = 512 outer updates (separate rocprofv3 --pmc passes, committed)
+                         "pmc_counters": pmc_mfma,
                          "lu_streams": os.environ.get("MAUS_LU_STREAMS", "1"),
                          "isolated_single_stream_pass": None if iso is None else {
                              "matrices": iso_active,
@@ -594,6 +615,10 @@ def main():
             "hbm_bound_kernels": hbm_kernels,
             "step_tflops": (8.0 / 3.0 * n ** 3 + 24.0 * n * n) * steps_done / elapsed / 1e12,
             "step_frac_of_mfma_peak": (8.0 / 3.0 * n ** 3 + 24.0 * n * n) * steps_done / elapsed / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            # the same in the convention of roofline.frac: flops EXECUTED on the matrix pipe (the LU's 8/3 n^3 run as 3M
+            # products, 0.75 of them; the 24 n^2 of the population products as 4M)
+            "step_frac_of_mfma_peak_executed": ((0.75 if os.environ.get("MAUS_GEMM_3M", "1") != "0" else 1.0) * 8.0 / 3.0 * n ** 3 + 24.0 * n * n)
+                                               * steps_done / elapsed / 1e12 / FP64_MFMA_PEAK_TFLOPS,
             "small_batch_rates": small,
         }
         if world == 1 and not args.no_cpu_baseline:
