@@ -18,7 +18,7 @@ SYMBOLS = [
     "maus_ctx_create", "maus_ctx_destroy", "maus_last_error", "maus_device_info", "maus_abi_version",
     "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get", "maus_pop_copy", "maus_pop_device_ptr", "maus_hist_append", "maus_hist_get", "maus_hist_clear", "maus_hist_generation",
     "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_lu_reserve", "maus_lu_workspace_allocs", "maus_set_shared_device", "maus_lu_mw_aborts", "maus_relax_normalise", "maus_residual",
-    "maus_svd_power_step", "maus_svd_power_propose", "maus_svd_commit", "maus_set_eigvecs", "maus_herm_match", "maus_gmres", "maus_gmres_pert", "maus_jacobi_check",
+    "maus_svd_power_step", "maus_svd_power_propose", "maus_svd_commit", "maus_set_eigvecs", "maus_herm_match", "maus_herm_tridiag", "maus_herm_backtransform", "maus_get_eigvecs", "maus_gmres", "maus_gmres_pert", "maus_jacobi_check",
     "maus_profile_union_ms", "maus_gram", "maus_zgemm_host", "maus_zgemm_bench", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
     "maus_profile_enable", "maus_profile_read", "maus_sync", "maus_mt19937_jump",
     "maus_device_count", "maus_comm_unique_id", "maus_comm_init", "maus_comm_destroy", "maus_comm_info",
@@ -91,6 +91,9 @@ def load_library():
         "maus_svd_commit": ([vp, vp, C.c_int], C.c_int),
         "maus_set_eigvecs": ([vp, vp, C.c_int], C.c_int),
         "maus_herm_match": ([vp, vp, C.c_int, vp, vp], C.c_int),
+        "maus_herm_tridiag": ([vp, vp, vp], C.c_int),
+        "maus_herm_backtransform": ([vp, vp, C.c_int], C.c_int),
+        "maus_get_eigvecs": ([vp, vp, C.c_int], C.c_int),
         "maus_gmres": ([vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_int, C.c_int, vp, vp, vp], C.c_int),
         "maus_gmres_pert": ([vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, C.c_double, C.c_int, C.c_int, vp, vp, vp, vp], C.c_int),
         "maus_jacobi_check": ([vp, C.c_int, vp, vp, vp], C.c_int),
@@ -235,6 +238,12 @@ class Context:
         V = _c128(V)
         self._ck(self.lib.maus_set_eigvecs(self.h, _ptr(V), V.shape[0]), "maus_set_eigvecs")
 
+    def get_eigvecs(self):
+        n = self.rows
+        V = np.empty((n, n), dtype=np.complex128)
+        self._ck(self.lib.maus_get_eigvecs(self.h, _ptr(V), n), "maus_get_eigvecs")
+        return V
+
     # -- population ----------------------------------------------------------
     def pop_reserve(self, cap):
         self._ck(self.lib.maus_pop_reserve(self.h, int(cap)), "maus_pop_reserve")
@@ -356,6 +365,26 @@ class Context:
         norms = np.empty((s.shape[0], 4), dtype=np.float64)
         self._ck(self.lib.maus_svd_power_step(self.h, _ptr(s), s.shape[0], _ptr(norms)), "maus_svd_power_step")
         return norms
+
+    def herm_tridiag(self):
+        """A = Q T Q^H of the bound Hermitian matrix on the device (zhetrd semantics): (d[n], e[n-1]) of the real T."""
+        n = self.rows
+        d = np.empty(n, dtype=np.float64)
+        e = np.empty(max(n - 1, 1), dtype=np.float64)
+        self._ck(self.lib.maus_herm_tridiag(self.h, _ptr(d), _ptr(e)), "maus_herm_tridiag")
+        return d, e[: n - 1]
+
+    def herm_backtransform(self, Z):
+        """V = Q Z on the device from the real eigenvectors Z[n][n] of T; V becomes the context's eigenvector matrix.  A
+        column-major Z (what LAPACK returns) is passed as it is and transposed on the device."""
+        Z = np.asarray(Z, dtype=np.float64)
+        if Z.shape != (self.rows, self.rows):
+            raise ValueError("herm_backtransform: Z must be n x n")
+        if Z.flags.f_contiguous and not Z.flags.c_contiguous:
+            self._ck(self.lib.maus_herm_backtransform(self.h, _ptr(Z.T), 1), "maus_herm_backtransform")
+        else:
+            Z = np.ascontiguousarray(Z)
+            self._ck(self.lib.maus_herm_backtransform(self.h, _ptr(Z), 0), "maus_herm_backtransform")
 
     def svd_power_propose(self, slots):
         """The power step without its effect: norms as svd_power_step, proposed u / v left in POP_Y / POP_W."""

@@ -116,7 +116,7 @@ int maus_ctx_destroy(maus_ctx* c) {
     (void)hipStreamSynchronize(c->st);
     (void)maus_comm_destroy(c);
     void* ptrs[] = {c->A, c->b, c->V, c->X, c->U, c->W, c->Y, c->d_slots, c->d_i1, c->d_i2, c->d_c1, c->d_c2, c->d_r1, c->d_r2,
-                    c->H, c->ipiv, c->perm, c->mw_sync, c->info, c->flags, c->Upert, c->scratch};
+                    c->H, c->ipiv, c->perm, c->mw_sync, c->info, c->flags, c->Upert, c->scratch, c->hq, c->htau};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     hist_free(c);
     for (auto& kv : c->mt_taps) if (kv.second.first) (void)hipFree(kv.second.first);
@@ -167,6 +167,7 @@ int maus_set_matrix(maus_ctx* c, const double* a, int rows, int cols) {
         HIPCHK(c, hipMalloc((void**)&c->A, sizeof(c128) * (size_t)rows * cols));
         c->rows = rows; c->cols = cols;
     }
+    if (c->hq) { (void)hipFree(c->hq); c->hq = nullptr; } if (c->htau) { (void)hipFree(c->htau); c->htau = nullptr; } c->hqn = 0;   // reflectors of the previous matrix
     HIPCHK(c, hipMemcpy(c->A, a, sizeof(c128) * (size_t)rows * cols, hipMemcpyHostToDevice));
     return 0;
 }
@@ -184,6 +185,13 @@ int maus_set_eigvecs(maus_ctx* c, const double* v, int n) {
     HIPCHK(c, hipStreamSynchronize(c->st));
     if (n != c->vn) { if (c->V) (void)hipFree(c->V); c->V = nullptr; HIPCHK(c, hipMalloc((void**)&c->V, sizeof(c128) * (size_t)n * n)); c->vn = n; }
     HIPCHK(c, hipMemcpy(c->V, v, sizeof(c128) * (size_t)n * n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int maus_get_eigvecs(maus_ctx* c, double* v_out, int n) {
+    if (!c->V || c->vn != n || !v_out) FAIL(c, "maus_get_eigvecs: no eigenvector matrix of that order on the device");
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipMemcpy(v_out, c->V, sizeof(c128) * (size_t)n * n, hipMemcpyDeviceToHost));
     return 0;
 }
 

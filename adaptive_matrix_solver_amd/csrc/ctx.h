@@ -52,6 +52,7 @@ struct maus_ctx {
     c128* A = nullptr; int rows = 0, cols = 0;      // problem matrix
     c128* b = nullptr; int bn = 0;                  // rhs
     c128* V = nullptr; int vn = 0;                  // eigenvectors (Hermitian shortcut)
+    c128* hq = nullptr; c128* htau = nullptr; int hqn = 0;   // Householder reflectors of maus_herm_tridiag, until the back-transformation (herm.hip)
     int cap = 0; long ldp = 0;                      // population
     c128 *X = nullptr, *U = nullptr, *W = nullptr, *Y = nullptr;
     // per-call scalar staging (device), sized for `scal_cap` candidates

@@ -1,0 +1,408 @@
+// Hermitian eigendecomposition on the device, the GEMM- and bandwidth-shaped parts of it (gfx950).
+//
+// Replaces the reduction and back-transformation inside the reference's once-per-candidate
+//     eigvals_h, eigvecs_h = scipy.linalg.eigh(A)                                  AMS:161
+// (LAPACK zheevr: zhetrd -> dstemr -> zunmtr; one decomposition per matrix here), which at n = 8192 costs 73 s
+// on the GPU box's host against 7 ms per loop body on the device:
+//   1. maus_herm_tridiag        A = Q T Q^H, zhetrd('L') semantics: blocked Householder tridiagonalisation, zlatrd panels of
+//                               64 columns + a rank-128 update of the trailing matrix per panel (one zgemm: [V W][W V]^H).
+//                               Half of the 16/3 n^3 flops are Hermitian matrix-vector products with the trailing matrix --
+//                               HBM-bound, 16/3 n^3 bytes with full storage -- the other half the MFMA zgemm.
+//   2. (host)                   the real symmetric tridiagonal eigenproblem, O(n^2): scipy.linalg.eigh_tridiagonal
+//                               (LAPACK dstemr, the same kernel zheevr uses) -- engine.py
+//   3. maus_herm_backtransform  V = Q Z, zunmtr semantics: blocks of 64 reflectors as I - V T V^H (zlarft), three zgemm
+//                               calls per block.
+// Phase convention: the reflectors are LAPACK's (zlarfg: beta real, v(1) = 1; H(i) acts on rows i+1..n-1), so Q e_1 = e_1
+// and the first row of V is the first row of the real Z -- LAPACK's "first component real".  The SIGN of a column is
+// whatever dstemr gives for T, and that is not reproducible across tridiagonalisations: dstemr fixes the sign at the twist
+// index of its factorisation, which moves under a 1-ulp change of T (one column in ten flips between LAPACK's own T and
+// the same T perturbed in the last bit, tests/test_gpu_herm_eigh.py).  Nothing downstream sees it: the distinctness and
+// redundancy tests take |<v, s>| (AMS:436, 515), a candidate converged through the shortcut is not stepped again.
+//
+// Per column i of a panel (m' = n-i-1), six small launches, nothing returns to the host until the end:
+//   colupd   a(i:n,i) -= V(i:n,0:j) conj(W(i,0:j)) + W(i:n,0:j) conj(V(i,0:j))            (row-parallel; partial |.|^2)
+//   larfg    xnorm from the partials in fixed order, beta / tau / scale, v -> panel column j and the reflector store
+//   hemv     w0 = A22 v   (A22 = the trailing matrix as the previous panels left it: this panel's reflectors come in below)
+//   dots     t1 = W(:,0:j)^H v, t2 = V(:,0:j)^H v
+//   wfin1    w = tau (w0 - V t1 - W t2); partial w^H v
+//   wfin2    w += (-1/2 tau w^H v) v  -> panel column j of W
+// All reductions run in a fixed order (no atomics), so a decomposition is reproducible bit for bit.
+#include "ctx.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+void maus_zgemm_launch(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA,
+                       const c128* B, long ldb, long sB, c128* C, long ldc, long sC,
+                       double alpha, int beta, int batch, int blay, bool conja, bool conjb);
+
+namespace {
+
+constexpr int HNB = 64;        // panel width / reflectors per block
+constexpr int HT = 256;        // threads of the row-parallel kernels
+
+__device__ __forceinline__ double block_sum_d(double v, double* sbuf) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) sbuf[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int q = 0; q < nw; ++q) s += sbuf[q];
+    return s;
+}
+
+// a(i:n, i) with the panel's earlier reflectors applied; col[r] for r in [i, n); part[block] = sum |a(r)|^2 over its rows >= i+2
+__global__ void __launch_bounds__(HT)
+herm_colupd_kernel(const c128* __restrict__ Aw, int n, int i, int j, const c128* __restrict__ PV, const c128* __restrict__ PW,
+                   c128* __restrict__ col, double* __restrict__ part)
+{
+    __shared__ c128 sw[HNB], sv[HNB];
+    __shared__ double sbuf[HT / 64];
+    const int tid = threadIdx.x;
+    if (tid < j) { sw[tid] = cconj(PW[(long)tid * n + i]); sv[tid] = cconj(PV[(long)tid * n + i]); }
+    __syncthreads();
+    const int r = i + blockIdx.x * HT + tid;
+    double ss = 0.0;
+    if (r < n) {
+        c128 a = Aw[(long)r * n + i];
+        for (int k = 0; k < j; ++k) { cfms(a, PV[(long)k * n + r], sw[k]); cfms(a, PW[(long)k * n + r], sv[k]); }
+        col[r] = a;
+        if (r >= i + 2) ss = fma(a.x, a.x, a.y * a.y);
+    }
+    ss = block_sum_d(ss, sbuf);
+    if (tid == 0) part[blockIdx.x] = ss;
+}
+
+// zlarfg on (alpha = col[i+1], x = col[i+2:n]); d[i], e[i], tau[i]; v -> PV[j] and VQ[i] (zeros above, 1 at i+1)
+__global__ void __launch_bounds__(1024)
+herm_larfg_kernel(const c128* __restrict__ col, int n, int i, int j, const double* __restrict__ part, int nparts,
+                  c128* __restrict__ PV, c128* __restrict__ VQ, c128* __restrict__ tau, double* __restrict__ d, double* __restrict__ e)
+{
+    __shared__ c128 s_scal;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        d[i] = col[i].x;
+        if (i + 1 < n) {
+            double ss = 0.0;
+            for (int q = 0; q < nparts; ++q) ss += part[q];
+            const double xnorm = sqrt(ss);
+            const c128 alpha = col[i + 1];
+            c128 t = cmake(0.0, 0.0), scal = cmake(0.0, 0.0);
+            double beta = alpha.x;
+            if (!(xnorm == 0.0 && alpha.y == 0.0)) {
+                const double w = fmax(fmax(fabs(alpha.x), fabs(alpha.y)), xnorm);        // dlapy3
+                const double ax = alpha.x / w, ay = alpha.y / w, xn = xnorm / w;
+                const double nrm = w * sqrt(ax * ax + ay * ay + xn * xn);
+                beta = -copysign(nrm, alpha.x);
+                t = cmake((beta - alpha.x) / beta, -alpha.y / beta);
+                scal = crecip(cmake(alpha.x - beta, alpha.y));
+            }
+            tau[i] = t; e[i] = beta; s_scal = scal;
+        }
+    }
+    __syncthreads();
+    if (i + 1 >= n) return;
+    const c128 scal = s_scal;
+    c128* pv = PV + (long)j * n;
+    c128* vq = VQ + (long)i * n;
+    for (int r = tid; r < n; r += blockDim.x) {
+        c128 v = cmake(0.0, 0.0);
+        if (r == i + 1) v = cmake(1.0, 0.0);
+        else if (r > i + 1) v = cmul(col[r], scal);
+        pv[r] = v; vq[r] = v;
+    }
+}
+
+// w0[r] = sum_{c > i} Aw[r][c] v[c] for r > i: one wave per row, four rows per workgroup
+__global__ void __launch_bounds__(256)
+herm_hemv_kernel(const c128* __restrict__ Aw, int n, int i, const c128* __restrict__ v, c128* __restrict__ w0)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = i + 1 + blockIdx.x * 4 + wave;
+    if (r >= n) return;
+    const c128* row = Aw + (long)r * n;
+    c128 s0 = cmake(0.0, 0.0), s1 = s0, s2 = s0, s3 = s0;
+    int c = i + 1 + lane;
+    for (; c + 192 < n; c += 256) {
+        cfma(s0, row[c], v[c]); cfma(s1, row[c + 64], v[c + 64]); cfma(s2, row[c + 128], v[c + 128]); cfma(s3, row[c + 192], v[c + 192]);
+    }
+    for (; c < n; c += 64) cfma(s0, row[c], v[c]);
+    const double sr = wave_sum((s0.x + s1.x) + (s2.x + s3.x)), si = wave_sum((s0.y + s1.y) + (s2.y + s3.y));
+    if (lane == 0) w0[r] = cmake(sr, si);
+}
+
+// blocks 0..j-1: t[k] = W_k^H v ; blocks j..2j-1: t[j + k] = V_k^H v   (rows > i)
+__global__ void __launch_bounds__(HT)
+herm_dots_kernel(const c128* __restrict__ PV, const c128* __restrict__ PW, int n, int i, int j, const c128* __restrict__ v, c128* __restrict__ t)
+{
+    __shared__ double sbuf[HT / 64];
+    const int b = blockIdx.x;
+    const c128* p = (b < j) ? PW + (long)b * n : PV + (long)(b - j) * n;
+    c128 s = cmake(0.0, 0.0);
+    for (int r = i + 1 + threadIdx.x; r < n; r += HT) cfma_conj(s, p[r], v[r]);
+    const double sr = block_sum_d(s.x, sbuf), si = block_sum_d(s.y, sbuf);
+    if (threadIdx.x == 0) t[b] = cmake(sr, si);
+}
+
+// w = tau (w0 - V t2' - W t1'): LAPACK's order -- w -= V (W^H v), then w -= W (V^H v); partial sum_r conj(w_r) v_r
+__global__ void __launch_bounds__(HT)
+herm_wfin1_kernel(const c128* __restrict__ PV, const c128* __restrict__ PW, int n, int i, int j, const c128* __restrict__ v,
+                  const c128* __restrict__ w0, const c128* __restrict__ t, const c128* __restrict__ tau, c128* __restrict__ wbuf,
+                  c128* __restrict__ cpart)
+{
+    __shared__ c128 st[2 * HNB];
+    __shared__ double sbuf[HT / 64];
+    const int tid = threadIdx.x;
+    if (tid < 2 * j) st[tid] = t[tid];
+    __syncthreads();
+    const int r = i + 1 + blockIdx.x * HT + tid;
+    c128 dot = cmake(0.0, 0.0);
+    if (r < n) {
+        c128 w = w0[r];
+        for (int k = 0; k < j; ++k) cfms(w, PV[(long)k * n + r], st[k]);            // V (W^H v)
+        for (int k = 0; k < j; ++k) cfms(w, PW[(long)k * n + r], st[j + k]);        // W (V^H v)
+        w = cmul(tau[i], w);
+        wbuf[r] = w;
+        cfma_conj(dot, w, v[r]);
+    }
+    const double dr = block_sum_d(dot.x, sbuf), di = block_sum_d(dot.y, sbuf);
+    if (tid == 0) cpart[blockIdx.x] = cmake(dr, di);
+}
+
+// w += alpha v, alpha = -1/2 tau (w^H v); panel column j of W (zeros for rows <= i)
+__global__ void __launch_bounds__(HT)
+herm_wfin2_kernel(c128* __restrict__ PW, int n, int i, int j, const c128* __restrict__ v, const c128* __restrict__ wbuf,
+                  const c128* __restrict__ cpart, int nparts, const c128* __restrict__ tau)
+{
+    const int r = blockIdx.x * HT + threadIdx.x;
+    if (r >= n) return;
+    c128 w = cmake(0.0, 0.0);
+    if (r > i) {
+        c128 dot = cmake(0.0, 0.0);
+        for (int q = 0; q < nparts; ++q) dot = cadd(dot, cpart[q]);
+        const c128 th = cmul(tau[i], dot);
+        const c128 alpha = cmake(-0.5 * th.x, -0.5 * th.y);
+        w = wbuf[r];
+        cfma(w, alpha, v[r]);
+    }
+    PW[(long)j * n + r] = w;
+}
+
+// rows r0..n-1 of the panel as GEMM operands: P2[r][0:nb] = V, P2[r][nb:2nb] = W; Q2[r] = [W | V]   (row-major, ld = 2 nb)
+__global__ void __launch_bounds__(HT)
+herm_pack_kernel(const c128* __restrict__ PV, const c128* __restrict__ PW, int n, int r0, int nb, c128* __restrict__ P2, c128* __restrict__ Q2)
+{
+    const long e = (long)blockIdx.x * HT + threadIdx.x;            // over (n - r0) x nb, row index fastest: coalesced panel reads
+    const int m = n - r0;
+    if (e >= (long)m * nb) return;
+    const int k = (int)(e / m), rr = (int)(e - (long)k * m);
+    const c128 a = PV[(long)k * n + r0 + rr], b = PW[(long)k * n + r0 + rr];
+    c128* p = P2 + (long)rr * 2 * nb;
+    c128* q = Q2 + (long)rr * 2 * nb;
+    p[k] = a; p[nb + k] = b; q[k] = b; q[nb + k] = a;
+}
+
+// Vt[rr][k] = VQ[k0 + k][r0 + rr]: the block's reflectors as a row-major (n - r0) x nb operand
+__global__ void __launch_bounds__(HT)
+herm_vt_kernel(const c128* __restrict__ VQ, int n, int k0, int r0, int nb, c128* __restrict__ Vt)
+{
+    const long e = (long)blockIdx.x * HT + threadIdx.x;
+    const int m = n - r0;
+    if (e >= (long)m * nb) return;
+    const int k = (int)(e / m), rr = (int)(e - (long)k * m);
+    Vt[(long)rr * nb + k] = VQ[(long)(k0 + k) * n + r0 + rr];
+}
+
+// zlarft (forward, columnwise): T upper triangular nb x nb (row-major, ld = HNB) from G = V^H V and tau
+__global__ void __launch_bounds__(64)
+herm_larft_kernel(const c128* __restrict__ G, int nb, const c128* __restrict__ tau, c128* __restrict__ T)
+{
+    __shared__ c128 sT[HNB][HNB + 1];
+    const int ii = threadIdx.x;                                    // row of T
+    for (int c = 0; c < nb; ++c) sT[ii][c] = cmake(0.0, 0.0);
+    __syncthreads();
+    for (int jj = 0; jj < nb; ++jj) {
+        const c128 tj = tau[jj];
+        if (ii < jj) {
+            c128 s = cmake(0.0, 0.0);
+            for (int l = ii; l < jj; ++l) cfma(s, sT[ii][l], G[(long)l * HNB + jj]);
+            const c128 m = cmul(tj, s);
+            sT[ii][jj] = cmake(-m.x, -m.y);
+        } else if (ii == jj) sT[ii][jj] = tj;
+        __syncthreads();
+    }
+    if (ii < nb) for (int c = 0; c < nb; ++c) T[(long)ii * HNB + c] = sT[ii][c];
+}
+
+__global__ void __launch_bounds__(HT)
+herm_real_to_complex_kernel(const double* __restrict__ Z, long count, c128* __restrict__ V)
+{
+    const long e = (long)blockIdx.x * HT + threadIdx.x;
+    if (e < count) V[e] = cmake(Z[e], 0.0);
+}
+
+// V[r][k] = Zt[k][r] + 0i: LAPACK hands the eigenvectors of T back column-major, i.e. as the transpose in C order -- turned
+// here through a 32 x 32 LDS tile instead of by a 512 MB transposition on the host (seconds at n = 8192)
+__global__ void __launch_bounds__(256)
+herm_transpose_to_complex_kernel(const double* __restrict__ Zt, int n, c128* __restrict__ V)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int k0 = blockIdx.y * 32, r0 = blockIdx.x * 32;
+    for (int q = ty; q < 32; q += 8) { const int k = k0 + q, r = r0 + tx; tile[q][tx] = (k < n && r < n) ? Zt[(long)k * n + r] : 0.0; }
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) { const int r = r0 + q, k = k0 + tx; if (r < n && k < n) V[(long)r * n + k] = cmake(tile[tx][q], 0.0); }
+}
+
+}  // namespace
+
+extern "C" {
+
+// MAUS_HERM_TIMING=1: host wall time of the phases on stderr (allocation of GiB-sized buffers is not free)
+struct HermClock {
+    bool on; std::chrono::steady_clock::time_point t;
+    HermClock() : on(getenv("MAUS_HERM_TIMING") && atoi(getenv("MAUS_HERM_TIMING"))), t(std::chrono::steady_clock::now()) {}
+    void lap(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[maus_herm] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
+static void herm_free(maus_ctx* c) {
+    if (c->hq) { (void)hipFree(c->hq); c->hq = nullptr; }
+    if (c->htau) { (void)hipFree(c->htau); c->htau = nullptr; }
+    c->hqn = 0;
+}
+
+int maus_herm_tridiag(maus_ctx* c, double* d_out, double* e_out) {
+    if (!c->A || c->rows != c->cols) FAIL(c, "maus_herm_tridiag: square matrix required (maus_set_matrix)");
+    if (!d_out || (!e_out && c->rows > 1)) FAIL(c, "maus_herm_tridiag: null output");
+    const int n = c->rows;
+    HermClock clk;
+    herm_free(c);
+    const size_t nn = (size_t)n * n;
+    c128 *Aw = nullptr, *PV = nullptr, *PW = nullptr, *P2 = nullptr, *Q2 = nullptr, *col = nullptr, *w0 = nullptr, *wbuf = nullptr, *t = nullptr, *cpart = nullptr;
+    double *part = nullptr, *d = nullptr, *e = nullptr;
+    const int nparts_max = (n + HT - 1) / HT;
+    auto cleanup = [&]() {
+        void* ps[] = {Aw, PV, PW, P2, Q2, col, w0, wbuf, t, cpart, part, d, e};
+        for (void* p : ps) if (p) (void)hipFree(p);
+    };
+#define HERM_ALLOC(ptr, bytes) do { if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { (void)hipGetLastError(); cleanup(); herm_free(c); \
+        FAIL(c, "maus_herm_tridiag: out of device memory"); } } while (0)
+    HERM_ALLOC(Aw, sizeof(c128) * nn);
+    HERM_ALLOC(c->hq, sizeof(c128) * nn);
+    HERM_ALLOC(c->htau, sizeof(c128) * n);
+    HERM_ALLOC(PV, sizeof(c128) * (size_t)HNB * n);
+    HERM_ALLOC(PW, sizeof(c128) * (size_t)HNB * n);
+    HERM_ALLOC(P2, sizeof(c128) * (size_t)2 * HNB * n);
+    HERM_ALLOC(Q2, sizeof(c128) * (size_t)2 * HNB * n);
+    HERM_ALLOC(col, sizeof(c128) * n);
+    HERM_ALLOC(w0, sizeof(c128) * n);
+    HERM_ALLOC(wbuf, sizeof(c128) * n);
+    HERM_ALLOC(t, sizeof(c128) * 2 * HNB);
+    HERM_ALLOC(cpart, sizeof(c128) * nparts_max);
+    HERM_ALLOC(part, sizeof(double) * nparts_max);
+    HERM_ALLOC(d, sizeof(double) * n);
+    HERM_ALLOC(e, sizeof(double) * n);
+#undef HERM_ALLOC
+    c->hqn = n;
+    clk.lap("tridiag: allocations");
+    hipStream_t st = c->st;
+    hipError_t err = hipMemcpyAsync(Aw, c->A, sizeof(c128) * nn, hipMemcpyDeviceToDevice, st);
+    if (err == hipSuccess) err = hipMemsetAsync(c->htau, 0, sizeof(c128) * n, st);
+    if (err == hipSuccess) err = hipMemsetAsync(c->hq, 0, sizeof(c128) * nn, st);
+    if (err == hipSuccess) err = hipMemsetAsync(e, 0, sizeof(double) * n, st);
+    for (int i0 = 0; i0 < n && err == hipSuccess; i0 += HNB) {
+        const int nb = (n - i0 < HNB) ? n - i0 : HNB;
+        for (int j = 0; j < nb; ++j) {
+            const int i = i0 + j, m = n - i, mp = n - i - 1;
+            const int np1 = (m + HT - 1) / HT;
+            hipLaunchKernelGGL(herm_colupd_kernel, dim3(np1), dim3(HT), 0, st, Aw, n, i, j, PV, PW, col, part);
+            hipLaunchKernelGGL(herm_larfg_kernel, dim3(1), dim3(1024), 0, st, col, n, i, j, part, np1, PV, c->hq, c->htau, d, e);
+            if (mp <= 0) continue;
+            const c128* v = PV + (size_t)j * n;
+            hipLaunchKernelGGL(herm_hemv_kernel, dim3((mp + 3) / 4), dim3(256), 0, st, Aw, n, i, v, w0);
+            if (j > 0) hipLaunchKernelGGL(herm_dots_kernel, dim3(2 * j), dim3(HT), 0, st, PV, PW, n, i, j, v, t);
+            const int np2 = (mp + HT - 1) / HT;
+            hipLaunchKernelGGL(herm_wfin1_kernel, dim3(np2), dim3(HT), 0, st, PV, PW, n, i, j, v, w0, t, c->htau, wbuf, cpart);
+            hipLaunchKernelGGL(herm_wfin2_kernel, dim3((n + HT - 1) / HT), dim3(HT), 0, st, PW, n, i, j, v, wbuf, cpart, np2, c->htau);
+        }
+        const int r0 = i0 + nb, M = n - r0;
+        if (M > 0) {
+            // A22 -= V W^H + W V^H as ONE product [V W] [W V]^H (K = 2 nb), both triangles (the matvecs read full rows)
+            hipLaunchKernelGGL(herm_pack_kernel, dim3((unsigned)(((long)M * nb + HT - 1) / HT)), dim3(HT), 0, st, PV, PW, n, r0, nb, P2, Q2);
+            ProfScope ps(c, KC_GEMM, 8.0 * M * (double)M * 2 * nb, 16.0 * ((double)M * 4 * nb + 2.0 * M * M));
+            maus_zgemm_launch(st, M, M, 2 * nb, P2, 2 * nb, 0, Q2, 2 * nb, 0, Aw + (size_t)r0 * n + r0, n, 0, -1.0, 1, 1, 1, false, true);
+        }
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipMemcpyAsync(d_out, d, sizeof(double) * n, hipMemcpyDeviceToHost, st);
+    if (err == hipSuccess && n > 1) err = hipMemcpyAsync(e_out, e, sizeof(double) * (n - 1), hipMemcpyDeviceToHost, st);
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    if (err == hipSuccess) err = hipGetLastError();
+    clk.lap("tridiag: enqueue + kernels");
+    cleanup();
+    clk.lap("tridiag: frees");
+    if (err != hipSuccess) { herm_free(c); char buf[256]; snprintf(buf, sizeof buf, "maus_herm_tridiag failed: %s", hipGetErrorString(err)); c->err = buf; return -1; }
+    return 0;
+}
+
+int maus_herm_backtransform(maus_ctx* c, const double* z_real, int col_major) {
+    const int n = c->rows;
+    if (!c->hq || c->hqn != n || n != c->cols) FAIL(c, "maus_herm_backtransform: no reflectors for this matrix (maus_herm_tridiag first)");
+    if (!z_real) FAIL(c, "maus_herm_backtransform: null input");
+    HermClock clk;
+    const size_t nn = (size_t)n * n;
+    if (c->vn != n) { if (c->V) (void)hipFree(c->V); c->V = nullptr; c->vn = 0; HIPCHK(c, hipMalloc((void**)&c->V, sizeof(c128) * nn)); c->vn = n; }
+    double* Zr = nullptr; c128 *Vt = nullptr, *G = nullptr, *T = nullptr, *X = nullptr, *Y = nullptr;
+    auto cleanup = [&]() { void* ps[] = {Zr, Vt, G, T, X, Y}; for (void* p : ps) if (p) (void)hipFree(p); };
+#define HERM_ALLOC(ptr, bytes) do { if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { (void)hipGetLastError(); cleanup(); \
+        FAIL(c, "maus_herm_backtransform: out of device memory"); } } while (0)
+    HERM_ALLOC(Zr, sizeof(double) * nn);
+    HERM_ALLOC(Vt, sizeof(c128) * (size_t)HNB * n);
+    HERM_ALLOC(G, sizeof(c128) * HNB * HNB);
+    HERM_ALLOC(T, sizeof(c128) * HNB * HNB);
+    HERM_ALLOC(X, sizeof(c128) * (size_t)HNB * n);
+    HERM_ALLOC(Y, sizeof(c128) * (size_t)HNB * n);
+#undef HERM_ALLOC
+    clk.lap("backtransform: allocations");
+    hipStream_t st = c->st;
+    hipError_t err = hipMemcpyAsync(Zr, z_real, sizeof(double) * nn, hipMemcpyHostToDevice, st);
+    if (clk.on) { (void)hipStreamSynchronize(st); clk.lap("backtransform: upload of Z"); }
+    if (err == hipSuccess) {
+        if (col_major) hipLaunchKernelGGL(herm_transpose_to_complex_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, st, Zr, n, c->V);
+        else hipLaunchKernelGGL(herm_real_to_complex_kernel, dim3((unsigned)((nn + HT - 1) / HT)), dim3(HT), 0, st, Zr, (long)nn, c->V);
+    }
+    const int nref = n - 1;                                   // reflectors H(0) .. H(n-2)
+    const int nblocks = (nref + HNB - 1) / HNB;
+    for (int b = nblocks - 1; b >= 0 && err == hipSuccess; --b) {
+        const int k0 = b * HNB, nb = (nref - k0 < HNB) ? nref - k0 : HNB;
+        const int r0 = k0 + 1, m = n - r0;                    // the block's reflectors are zero above row k0 + 1
+        const c128* Vq = c->hq + (size_t)k0 * n + r0;         // [k][r], ld = n
+        c128* Zs = c->V + (size_t)r0 * n;
+        // G = V^H V (nb x nb), T from it (zlarft)
+        maus_zgemm_launch(st, nb, nb, m, Vq, n, 0, Vq, n, 0, G, HNB, 0, 1.0, 0, 1, 1, true, false);
+        hipLaunchKernelGGL(herm_larft_kernel, dim3(1), dim3(64), 0, st, G, nb, c->htau + k0, T);
+        hipLaunchKernelGGL(herm_vt_kernel, dim3((unsigned)(((long)m * nb + HT - 1) / HT)), dim3(HT), 0, st, c->hq, n, k0, r0, nb, Vt);
+        {   ProfScope ps(c, KC_GEMM, 8.0 * nb * (double)n * m * 2 + 8.0 * nb * (double)nb * n, 16.0 * ((double)m * n * 3));
+            maus_zgemm_launch(st, nb, n, m, Vq, n, 0, Zs, n, 0, X, n, 0, 1.0, 0, 1, 0, true, false);         // X = V^H Z
+            maus_zgemm_launch(st, nb, n, nb, T, HNB, 0, X, n, 0, Y, n, 0, 1.0, 0, 1, 0, false, false);       // Y = T X
+            maus_zgemm_launch(st, m, n, nb, Vt, nb, 0, Y, n, 0, Zs, n, 0, -1.0, 1, 1, 0, false, false);      // Z -= V Y
+        }
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    if (err == hipSuccess) err = hipGetLastError();
+    clk.lap("backtransform: kernels");
+    cleanup();
+    herm_free(c);                                            // the reflectors are only good for this one back-transformation
+    clk.lap("backtransform: frees");
+    if (err != hipSuccess) { char buf[256]; snprintf(buf, sizeof buf, "maus_herm_backtransform failed: %s", hipGetErrorString(err)); c->err = buf; return -1; }
+    return 0;
+}
+
+}  // extern "C"

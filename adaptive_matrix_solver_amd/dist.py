@@ -217,11 +217,13 @@ class PopulationComm:
         afterwards.  rccl: uploaded once and broadcast device to device; gloo: host broadcast, then each rank uploads."""
         if self.transport == "rccl":
             t0 = time.perf_counter()
-            if self.rank == root:
+            if self.rank == root and evecs is not None:      # None: already resident on the root's device (device_eigh)
                 ctx.set_eigvecs(evecs)
             self._need_ctx().comm_bcast_eigvecs(n, root)
             self._account(t0, 16 * n * n)
             return
+        if self.rank == root and evecs is None:
+            evecs = ctx.get_eigvecs()
         V = np.ascontiguousarray(evecs, dtype=np.complex128) if self.rank == root else np.empty((n, n), dtype=np.complex128)
         self.bcast_array(V.view(np.float64), root)
         ctx.set_eigvecs(V)

@@ -80,6 +80,7 @@ class _AsyncStreamAdvance:
         self.thread.join()
 
 
+EIGH_DEVICE_MIN = 1536                     # eigh_mode='auto': device reduction / back-transformation from this order up
 COND_THRESHOLDS = (1e6, 1e12, 1e15)        # AMS:401, 407-416: the only places the condition number is used
 COND_GUARD = 30.0                          # an estimate this close (either side) to a threshold is not trusted
 
@@ -155,8 +156,12 @@ class DeviceEngine:
     _default = None
 
     def __init__(self, device: int = 0, pert_mode: str = "auto", gmres_compat: str = "rtol",
-                 comm=None, ctx=None):
+                 comm=None, ctx=None, eigh_mode: str = "auto"):
         self.ctx = ctx if ctx is not None else _cabi.Context(device)
+        # Hermitian eigendecomposition (AMS:161), once per matrix: 'host' = scipy.linalg.eigh, the reference's call, (lambda, V)
+        # bit-identical to its; 'device' = reduction and back-transformation on the GPU, the tridiagonal eigenproblem by LAPACK
+        # dstemr on the host (csrc/herm.hip); 'auto' = device from n = EIGH_DEVICE_MIN up.  MAUS_EIGH overrides.
+        self.eigh_mode = os.environ.get("MAUS_EIGH", eigh_mode)
         self._owner = {}                        # id(candidate) -> rank that executes it this step
         self.pert_mode = pert_mode              # 'auto' | 'uniform' | 'mt19937' | 'none'
         self.gmres_compat = gmres_compat        # 'rtol' | 'scipy-legacy'  
@@ -480,8 +485,30 @@ class DeviceEngine:
     def seed_eigh(self, A, evals, evecs):
         """eigh(A) computed by the caller (the start-up diagnostics took the condition number from it): use it as the
         once-per-matrix decomposition of the shortcut."""
-        self.ctx.set_eigvecs(evecs)
+        if evecs is not None:                   # None: device_eigh left V resident on the device
+            self.ctx.set_eigvecs(evecs)
         self._eig_cache = (A, evals)
+
+    def use_device_eigh(self, n: int) -> bool:
+        if not hasattr(self.ctx, "herm_tridiag") or self.eigh_mode == "host":
+            return False
+        return self.eigh_mode == "device" or n >= EIGH_DEVICE_MIN
+
+    def device_eigh(self, A):
+        """scipy.linalg.eigh(A) (LAPACK zheevr = zhetrd + dstemr + zunmtr) with zhetrd and zunmtr on the device: eigenvalues
+        on the host, the eigenvector matrix resident on the device as if uploaded with set_eigvecs.  Same reflector
+        conventions as LAPACK (first row of V real); the sign of a column is dstemr's for our T and differs from the
+        reference's in about one column out of ten -- as it does between LAPACK's own T and that T moved by one ulp.
+        73 s -> seconds at n = 8192."""
+        import scipy.linalg as sla
+        self.bind_matrix(A)
+        d, e = self.ctx.herm_tridiag()
+        if A.shape[0] == 1:
+            evals, Z = d.copy(), np.ones((1, 1))
+        else:
+            evals, Z = sla.eigh_tridiagonal(d, e)                  # LAPACK dstemr: the kernel zheevr uses
+        self.ctx.herm_backtransform(Z)
+        return evals
 
     def _eigh_once(self, A):
         """One decomposition per matrix version instead of one per candidate; the same LAPACK call as the
@@ -492,8 +519,11 @@ class DeviceEngine:
         import scipy.linalg as sla
         comm = self.comm
         n = A.shape[0]
+        dev = self.use_device_eigh(n)
         if comm is None or comm.world == 1:
             try:
+                if dev:
+                    return self.device_eigh(A), None
                 evals, evecs = sla.eigh(A)
             except np.linalg.LinAlgError as e:
                 return None, str(e)
@@ -503,7 +533,10 @@ class DeviceEngine:
         if comm.rank == 0:
             try:
                 with comm.all_blas_threads():
-                    ev, evecs = sla.eigh(A)
+                    if dev:
+                        ev = self.device_eigh(A)                   # V stays on rank 0's device; broadcast from there
+                    else:
+                        ev, evecs = sla.eigh(A)
                 evals[:] = ev
             except np.linalg.LinAlgError as e:
                 err = str(e) or "eigh failed"

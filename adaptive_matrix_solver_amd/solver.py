@@ -418,7 +418,7 @@ class MAUS_Solver:
     def __init__(self, problem_matrix, problem_type, b_vector=None, initial_num_candidates=None,
                  global_convergence_tol=1e-8, *, device=0, pert_mode="auto", gmres_compat="rtol",
                  record_history=None, comm=None, quiet=False, engine=None, gram_min=8, cond_exact_max=1024,
-                 diag_info=None):
+                 diag_info=None, eigh_mode="auto"):
         if _is_sparse(problem_matrix):
             raise NotImplementedError("sparse problems are outside the MI355X hot path (dense only)")
         self.M = problem_matrix.astype(np.complex128)                                   # AMS:343
@@ -434,7 +434,7 @@ class MAUS_Solver:
         # `engine` is a test seam (tests/fake_ctx.py drives the host logic without a GPU); product
         # code never passes it, and DeviceEngine() raises if libmaus_hip / the device is missing
         self.engine = engine if engine is not None else DeviceEngine(device=device, pert_mode=pert_mode,
-                                                                     gmres_compat=gmres_compat, comm=comm)
+                                                                     gmres_compat=gmres_compat, comm=comm, eigh_mode=eigh_mode)
         # `diag_info`: start-up diagnostics of the same matrix taken from an earlier solver (bench side runs)
         if diag_info is not None:
             self.diag_info = dict(diag_info)
@@ -541,7 +541,10 @@ class MAUS_Solver:
                     # (44 s + 70 s at n = 8192, profiles/r02_c4_hermitian_8192_end_to_end.txt)
                     import scipy.linalg as sla
                     try:
-                        evals, evecs = sla.eigh(matrix)
+                        if self.engine.use_device_eigh(matrix.shape[0]):
+                            evals, evecs = self.engine.device_eigh(matrix), None       # V stays on the device
+                        else:
+                            evals, evecs = sla.eigh(matrix)
                         amax, amin = float(np.abs(evals).max()), float(np.abs(evals).min())
                         with np.errstate(divide="ignore"):
                             cond_num_val = np.float64(amax) / np.float64(amin)

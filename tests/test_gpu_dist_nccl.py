@@ -57,6 +57,11 @@ for n in names:
     if n == "herm16":
         V = np.linalg.qr(np.random.default_rng(1).standard_normal((16, 16)) + 0j)[0]
         comm.bcast_eigvecs(s.engine.ctx, V, 16)
+        # the decomposition with the reduction / back-transformation on the device leaves V resident on the root: broadcast from there
+        ev = s.engine.device_eigh(s.M)
+        comm.bcast_eigvecs(s.engine.ctx, None, 16)
+        Vd = s.engine.ctx.get_eigvecs()
+        assert np.linalg.norm(s.M @ Vd - Vd * ev[None, :]) < 1e-12 and np.abs(Vd[0].imag).max() == 0.0
     comm.barrier()
     stats.append(comm.stats())
     lib_stats = s.engine.ctx.comm_stats()
