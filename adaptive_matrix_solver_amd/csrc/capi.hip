@@ -284,7 +284,7 @@ int maus_pop_copy(maus_ctx* c, int which_dst, int which_src, const int* slots, i
 
 // ---- history store (AMS:126, 303-304: param_history keeps every iterate of every candidate) -------------------------
 // Rows are appended device-to-device (no PCIe traffic in the step) into fixed chunks that are never moved; a row is
-// addressed by its append index.  Beyond MAUS_HIST_DEVICE_BYTES (default 8 GiB) the oldest device chunk is spilled to
+// addressed by its append index.  Beyond MAUS_HIST_DEVICE_BYTES (default 1/8 of the device memory, at least 8 GiB) the oldest device chunk is spilled to
 // host memory, so the history can grow like the reference's Python lists do without taking HBM from the LU workspace.
 __global__ void hist_append_kernel(c128* __restrict__ dst, long len, const c128* __restrict__ src, long ld, const int* __restrict__ slots) {
     const c128* s = src + (long)slots[blockIdx.x] * ld;
@@ -311,8 +311,12 @@ int maus_hist_append(maus_ctx* c, int which, const int* slots, int count, int le
     if (count == 0) return 0;
     len = (int)c->ldp;                                               // rows are stored whole (u and v of an SVD problem differ in length)
     c->hist_len = len;
+    // device budget of the store: MAUS_HIST_DEVICE_BYTES, default 1/8 of the device's memory but at least 8 GiB (36 GB on an
+    // MI355X: BASELINE configs[4] appends 400 MB per loop body, and spilling a chunk to pageable host memory costs 20-40 ms)
+    static const size_t budget_default = [] { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); tot = 0; }
+                                              return std::max((size_t)8 << 30, tot / 8); }();
     const char* be = getenv("MAUS_HIST_DEVICE_BYTES");
-    const size_t budget = be ? (size_t)atoll(be) : ((size_t)8 << 30);
+    const size_t budget = be ? (size_t)atoll(be) : budget_default;
     const char* ce = getenv("MAUS_HIST_CHUNK_BYTES");                                                          // 256 MiB chunks
     const long chunk_rows = !c->hist.empty() ? c->hist.front().cap
                           : std::max<long>(4, (long)((ce ? (size_t)atoll(ce) : ((size_t)256 << 20)) / (sizeof(c128) * (size_t)len)));

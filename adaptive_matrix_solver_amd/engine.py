@@ -232,6 +232,7 @@ class DeviceEngine:
         """Give a candidate a device slot (and free it when the object dies)."""
         self.bind_matrix(cand.problem_matrix)
         cand._engine = self
+        cand.param_history.ctx = self.ctx
         cand._slot = self.alloc_slot()
         weakref.finalize(cand, DeviceEngine._release, weakref.ref(self), cand._slot, id(self._bound))
 
@@ -275,8 +276,14 @@ class DeviceEngine:
             iv = self.ctx.hist_append(POP_X, slots, lv)
             iu = self.ctx.hist_append(POP_U, slots, lazy[0].M_rows) if svd else None
             gen = self.ctx.hist_generation() if hasattr(self.ctx, "hist_generation") else 0      # once per step, not per candidate
-            for k, c in enumerate(lazy):
-                c._hist_ref = (((iu + k, c.M_rows), (iv + k, lv)) if svd else ((iv + k, lv),), gen)
+            # flat tuples of ints: solver.history_ref() without the tag and the scalar (SolutionCandidate._record_history adds them)
+            if svd:
+                lu = lazy[0].M_rows
+                for k, c in enumerate(lazy):
+                    c._hist_ref = (gen, iu + k, lu, iv + k, lv)
+            else:
+                for k, c in enumerate(lazy):
+                    c._hist_ref = (gen, iv + k, lv)
 
     # ---- perturbation mode ---------------------------------------------------------------
     def _pert(self, n: int) -> int:
@@ -983,7 +990,7 @@ class DeviceEngine:
         thr = strat.get("current_convergence_threshold", CONVERGENCE_RESIDUAL_TOL)
         self._stage_history(cands)
         prev = np.array([c.prev_residual for c in cands], dtype=np.float64)
-        alpha = np.array([c.alpha_local_step for c in cands], dtype=np.float64)
+        alpha = np.array([c.alpha_local_step.real for c in cands], dtype=np.float64)      # np.complex128(0.01) in the reference (AMS:17): the imaginary part is always 0
         with np.errstate(invalid="ignore", over="ignore"):
             live = prev > 1e-10                                                  # AMS:306
             m1 = live & (resv < prev * 0.9)                                      # AMS:307 -> REFINING

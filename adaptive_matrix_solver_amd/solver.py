@@ -201,15 +201,35 @@ class _HistRef:
         return vecs if self.scalar is None else (self.scalar,) + vecs
 
 
+_HREF = "\x00maus-history-row"        # first item of a compact history reference (see _LazyHistory)
+
+
+def history_ref(scalar, gen, rows):
+    """Compact form of a _HistRef inside param_history: an exact tuple of atoms (tag, scalar, store generation, index, length
+    [, index, length]).  The cyclic garbage collector stops tracking such a tuple at its first pass, whereas one _HistRef
+    instance per candidate and step stays tracked for good: at 6 144 candidates (BASELINE configs[4]) that was half a million
+    tracked objects after 20 loop bodies and a full collection of 12-33 ms every third body (tools/gc_probe.py)."""
+    return (_HREF, scalar, gen) + tuple(rows)
+
+
+def is_history_ref(entry) -> bool:
+    return type(entry) is tuple and len(entry) >= 5 and entry[0] is _HREF
+
+
 class _LazyHistory(list):
     """param_history (AMS:126, 303-304).  Entries recorded by the batched step above n = 512 are references into the
     device-backed history store and become the reference's tuples (lambda, v) / (x,) / (sigma, u, v) when they are
     read; everything else about the list (len, append, iteration, slicing) is a plain list."""
+    ctx = None                              # the context whose history store the references point into (set by DeviceEngine.attach)
 
     def _get(self, i):
         e = list.__getitem__(self, i)
         if isinstance(e, _HistRef):
             e = e.resolve()
+            list.__setitem__(self, i, e)
+        elif is_history_ref(e):
+            rows = tuple((e[k], e[k + 1]) for k in range(3, len(e), 2))
+            e = _HistRef(self.ctx, e[1], rows, e[2]).resolve()
             list.__setitem__(self, i, e)
         return e
 
@@ -388,8 +408,7 @@ class SolutionCandidate:
             if self._hist_ref is not None:
                 pt = self.problem_type
                 scalar = self.lambda_k if pt == ProblemType.EIGENVALUE else (self.sigma_k if pt == ProblemType.SVD else None)
-                rows, gen = self._hist_ref                        # staged by the engine: store rows + the store's generation
-                self.param_history.append(_HistRef(self._engine.ctx, scalar, rows, gen))
+                self.param_history.append((_HREF, scalar) + self._hist_ref)   # staged by the engine: (generation, index, length, ...)
                 self._hist_ref = None
             else:
                 self.param_history.append(self.get_current_solution_params())
