@@ -235,6 +235,30 @@ herm_larft_kernel(const c128* __restrict__ G, int nb, const c128* __restrict__ t
     if (ii < nb) for (int c = 0; c < nb; ++c) T[(long)ii * HNB + c] = sT[ii][c];
 }
 
+// The work copy as zheevr('L') sees the matrix: only the lower triangle counts.  The upper triangle becomes its mirror image and
+// the diagonal real, so that the full-row matvecs above compute what LAPACK's zhemv('L') computes -- also for an input that
+// is Hermitian only to np.allclose's tolerance (AMS:384: the reference's own test before it calls eigh).
+__global__ void __launch_bounds__(256)
+herm_mirror_lower_kernel(c128* __restrict__ Aw, int n)
+{
+    __shared__ c128 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int bi = blockIdx.y, bj = blockIdx.x;                      // tile (bi, bj) of the UPPER triangle, bj >= bi
+    if (bj < bi) return;
+    for (int q = ty; q < 32; q += 8) {                               // read the mirror tile (bj, bi) of the lower triangle
+        const int r = bj * 32 + q, c = bi * 32 + tx;
+        tile[q][tx] = (r < n && c < n) ? Aw[(long)r * n + c] : cmake(0.0, 0.0);
+    }
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {
+        const int r = bi * 32 + q, c = bj * 32 + tx;
+        if (r < n && c < n) {
+            if (c > r) Aw[(long)r * n + c] = cconj(tile[tx][q]);
+            else if (c == r) Aw[(long)r * n + c].y = 0.0;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(HT)
 herm_real_to_complex_kernel(const double* __restrict__ Z, long count, c128* __restrict__ V)
 {
@@ -313,6 +337,7 @@ int maus_herm_tridiag(maus_ctx* c, double* d_out, double* e_out) {
     clk.lap("tridiag: allocations");
     hipStream_t st = c->st;
     hipError_t err = hipMemcpyAsync(Aw, c->A, sizeof(c128) * nn, hipMemcpyDeviceToDevice, st);
+    if (err == hipSuccess) hipLaunchKernelGGL(herm_mirror_lower_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, st, Aw, n);
     if (err == hipSuccess) err = hipMemsetAsync(c->htau, 0, sizeof(c128) * n, st);
     if (err == hipSuccess) err = hipMemsetAsync(c->hq, 0, sizeof(c128) * nn, st);
     if (err == hipSuccess) err = hipMemsetAsync(e, 0, sizeof(double) * n, st);

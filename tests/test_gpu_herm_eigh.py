@@ -60,6 +60,23 @@ def test_tridiagonalisation_and_eigenvectors_against_lapack(ctx, n):
     assert flips <= max(2, n // 3), f"{flips} of {n} columns with the opposite sign: more than rounding explains"
 
 
+def test_only_the_lower_triangle_counts(ctx):
+    """scipy.linalg.eigh(A) reads the lower triangle (lower=True): an input that is Hermitian only to np.allclose's tolerance
+    (the reference's test, AMS:384) must give what LAPACK gives for its lower triangle."""
+    n = 150
+    A = scenarios.hermitian(n, 77)
+    rng = np.random.default_rng(6)
+    A = A + np.triu(1e-9 * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))), 1)      # upper triangle disturbed
+    A[np.diag_indices(n)] += 1e-9j
+    assert np.allclose(A, A.conj().T)
+    d, e, w, V = _device_eigh(ctx, A)
+    wl = sla.eigvalsh(A, lower=True)
+    assert np.abs(w - wl).max() <= 40 * n * EPS * np.linalg.norm(A, 2)
+    L = np.tril(A, -1)
+    Al = L + L.conj().T + np.diag(A.diagonal().real)
+    assert np.linalg.norm(Al @ V - V * w[None, :]) <= 1e-12
+
+
 def test_dstemr_signs_are_rounding():
     """Why (iv) compares modulo sign: LAPACK's own tridiagonal matrix against itself with d, e moved by one ulp."""
     from scipy.linalg import lapack
