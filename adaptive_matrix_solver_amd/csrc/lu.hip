@@ -585,6 +585,8 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
     bool aborted = false;         // workgroup-uniform: a rendezvous timed out (here or in a sibling workgroup)
     __syncthreads();
 
+    // (the barriers inside a column step order LDS traffic only -- lds_barrier -- : what travels through global memory is drained by
+    // its writer's own s_waitcnt and reaches LDS through a data dependence)
     // one instantiation per column (R is indexed by the column, so `a` must be a compile-time constant; a 16-fold
     // `#pragma unroll` of this body exceeds the unroller's size limit); after an abort the remaining steps are skipped
     PCLK(8);
@@ -609,7 +611,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
             if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
         }
         if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
-        __syncthreads();
+        lds_barrier();
         best = s_val[0]; bidx = s_idx[0];
 #pragma unroll
         for (int q = 1; q < PT / 64; ++q) {
@@ -631,7 +633,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
                 s_phys[1] = pr[k];
             }
         }
-        __syncthreads();
+        lds_barrier();
         PCLK(9);
         // ---- publish (wave 0: candidate, wave 1: row a), drain, arrive ----
         if (wave == 0) {
@@ -644,7 +646,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
             if (lane == 32) mw_store(&sy->aphys[par], (unsigned long long)(unsigned)s_phys[1]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __syncthreads();
+        lds_barrier();
         PCLK(10);
         if (tid == 0) {
             // test hook (MAUS_PANEL_MW_FORCE_ABORT): the last workgroup of matrix 0 skips its arrival at column 3, so its
@@ -662,7 +664,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        __syncthreads();
+        lds_barrier();
         PCLK(11);
         aborted = (s_abort != 0);
       }
@@ -682,7 +684,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
                 else s_phys[1] = (int)(unsigned)mw_load(&sy->aphys[par]);
             }
         }
-        __syncthreads();
+        lds_barrier();
         PCLK(12);
         double gv = -1.0; int gp = INT_MAX, gw = 0, gphys = 0;
         for (int q = 0; q < W; ++q) {
@@ -694,7 +696,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         const int p = none ? a : gp;
         if (tid < 2 * NBP) ((double*)s_row)[tid] = none ? ((const double*)s_arow)[tid] : s_all[gw][tid];
         if (tid == 0) s_phys[0] = none ? s_phys[1] : gphys;
-        __syncthreads();
+        lds_barrier();
         PCLK(13);
         // ---- the interchange: the owners of logical rows a and p exchange register rows and physical rows ----
         if (p != a) {
@@ -730,7 +732,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
                 for (int c = 0; c < NBP; ++c) if (c > a) cfms(R[k][c], l, s_row[c]);
             }
         }
-        __syncthreads();
+        lds_barrier();
         PCLK(14);
       }
     };

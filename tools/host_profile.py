@@ -40,5 +40,8 @@ for it in range(bodies):
 s.engine.ctx.sync()
 pr.disable(); el = time.perf_counter() - t0
 print(f"{cfg}: {act} candidate steps in {bodies} loop bodies, {el * 1e3:.1f} ms, {el / act * 1e6:.1f} us per candidate step")
-out = io.StringIO(); pstats.Stats(pr, stream=out).sort_stats("tottime").print_stats(32)
+out = io.StringIO(); st = pstats.Stats(pr, stream=out); st.sort_stats("tottime").print_stats(32)
 print("\n".join(l[:170] for l in out.getvalue().splitlines()[:48]))
+if len(sys.argv) > 3:                                      # callees of one function, e.g. _solve
+    out = io.StringIO(); st.stream = out; st.print_callees(sys.argv[3])
+    print("\n".join(l[:170] for l in out.getvalue().splitlines()[:60]))
