@@ -218,7 +218,7 @@ herm_vt_kernel(const c128* __restrict__ VQ, int n, int k0, int r0, int nb, c128*
 __global__ void __launch_bounds__(64)
 herm_larft_kernel(const c128* __restrict__ G, int nb, const c128* __restrict__ tau, c128* __restrict__ T)
 {
-    __shared__ c128 sT[HNB][HNB + 1];
+    __shared__ c128 sT[HNB][HNB];                                  // 64 KB
     const int ii = threadIdx.x;                                    // row of T
     for (int c = 0; c < nb; ++c) sT[ii][c] = cmake(0.0, 0.0);
     __syncthreads();

@@ -5,6 +5,7 @@ import json
 import os
 import random
 import socket
+import subprocess
 import sys
 import tempfile
 
@@ -150,3 +151,40 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     r = _bench(["--gpus", "4", "--launch-check"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0",
                                                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+_ID_CHILD = r'''
+import os, sys
+sys.path.insert(0, %r)
+from adaptive_matrix_solver_amd.dist import _exchange_unique_id
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+uid = _exchange_unique_id(rank, world, lambda: bytes(range(128)), timeout=60.0)
+assert len(uid) == 128
+sys.stdout.write(uid.hex())
+'''
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_rccl_id_exchange_between_real_processes(world):
+    """The 128-byte RCCL id travels from rank 0 to every other rank over a socket next to MASTER_PORT (dist._exchange_unique_id):
+    exercised here with real processes and a stand-in id (the RCCL call itself needs one GPU per rank).  A foreign listener on
+    the first candidate port must be skipped."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    squatter = socket.create_server(("127.0.0.1", port + 1))          # somebody else already listens where the id server would start
+    try:
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       TORCHELASTIC_RUN_ID="idtest")
+            procs.append(subprocess.Popen([sys.executable, "-c", _ID_CHILD % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = []
+        for p in procs:
+            out, err = p.communicate(timeout=120)
+            assert p.returncode == 0, err[-2000:]
+            outs.append(out.strip())
+        assert all(o == bytes(range(128)).hex() for o in outs), outs
+    finally:
+        squatter.close()
