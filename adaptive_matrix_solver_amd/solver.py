@@ -863,8 +863,9 @@ class MAUS_Solver:
 
     # ---- AMS:551-608 ------------------------------------------------------------------------------
     def _reference_solution(self):
-        """The reference's reporting prologue (AMS:554-570): a SciPy answer to compare the final report with.
-        O(n^3) on the host; evolve() runs it by default only up to n = 1024."""
+        """The reference's reporting prologue (AMS:554-570): a reference answer to compare the final report with.  Linear
+        systems above n = 512 on the device LU, Hermitian spectra and singular values from n = 1536 up through the device
+        tridiagonalisation (SURVEY f-4); general eigenvalues by SciPy on the host (O(n^3))."""
         import scipy.linalg as sla
         try:
             if self.M.size == 0:
@@ -872,6 +873,12 @@ class MAUS_Solver:
             if self.problem_type == ProblemType.EIGENVALUE:
                 if self.N_rows != self.N_cols:
                     raise ValueError("Non-square matrix for Eigenvalue.")
+                if self.problem_knowledge.get("is_hermitian", False) and self.engine.use_device_eigh(self.N_rows):
+                    # Hermitian: the spectrum of the tridiagonal matrix the device reduces M to (csrc/herm.hip) instead of a
+                    # general QR iteration on the host -- eigenvalues only (dsterf), real, in eigvals()'s sorted order
+                    self.engine.bind_matrix(self.M)
+                    d, e = self.engine.ctx.herm_tridiag()
+                    return np.sort(sla.eigvalsh_tridiagonal(d, e) if d.shape[0] > 1 else d).astype(np.complex128)
                 vals = sla.eigvals(self.M)
                 vals.sort()
                 return vals
@@ -891,6 +898,22 @@ class MAUS_Solver:
                     self.engine.bind_matrix(self.M)
                     return x[0]
                 return sla.solve(self.M, self.b, assume_a="general")
+            if self.engine.use_device_eigh(self.N_rows + self.N_cols) and np.all(np.isfinite(self.M)):
+                # singular values as the positive eigenvalues of the Hermitian embedding [[0, M], [M^H, 0]] (+-sigma_i and
+                # |rows - cols| zeros), reduced to tridiagonal form on the device: the same absolute accuracy eps ||M|| as
+                # LAPACK's bidiagonal SVD, without its O(n^3) on the host
+                r, c = self.N_rows, self.N_cols
+                Hm = np.zeros((r + c, r + c), dtype=np.complex128)
+                Hm[:r, r:] = self.M
+                Hm[r:, :r] = self.M.conj().T
+                cH = _cabi.Context(self.engine.ctx.device)
+                try:
+                    cH.set_matrix(Hm)
+                    d, e = cH.herm_tridiag()
+                finally:
+                    cH.close()
+                w = sla.eigvalsh_tridiagonal(d, e)
+                return np.maximum(np.sort(w)[::-1][: min(r, c)], 0.0).tolist()
             return sorted(sla.svd(self.M, compute_uv=False).tolist(), reverse=True)
         except (np.linalg.LinAlgError, ValueError) as e:
             print(f"NumPy reference calculation failed: {e}.")
