@@ -129,6 +129,74 @@ void reduce(std::vector<uint64_t>& a, Poly& r) {
     // clear anything at or above DEG (all zero after reduction)
 }
 
+// ---- Barrett reduction with carry-less multiplies (x86 PCLMULQDQ), round 3 -----------------------------------------------
+// The schoolbook reduce() above costs ~10 000 x 312 word XORs per call and x^J mod phi needs one per bit of J and more: 25-85 ms
+// per new J -- and the engine asks for a new J every loop body (the whole run's E3 consumption: 4 N^2 words x candidates), which
+// made 26 ms the floor of a GMRES loop body whose kernels take 12.  With mu = floor(x^(2 DEG) / phi) precomputed,
+//     q = floor( floor(a / x^DEG) * mu / x^DEG ),   a mod phi = (a xor q * phi) mod x^DEG          (deg a < 2 DEG; exact over GF(2))
+// is two products of 312-word polynomials: ~0.2 ms.  Falls back to reduce() on a CPU without PCLMULQDQ.
+#if defined(__x86_64__) && defined(__PCLMUL__)
+#include <smmintrin.h>
+#include <wmmintrin.h>
+#define MAUS_HAVE_CLMUL 1
+Poly g_barrett;                               // mu = floor(x^(2 DEG) / phi), degree DEG
+bool g_barrett_ok = false;
+
+// c[0 .. na+nb) = a * b over GF(2); if low_only > 0 only words below low_only are produced
+void pmul(const uint64_t* a, int na, const uint64_t* b, int nb, uint64_t* c, int low_only = 0) {
+    const int nc = low_only > 0 ? low_only : na + nb;
+    for (int k = 0; k < nc; ++k) c[k] = 0;
+    for (int i = 0; i < na; ++i) {
+        if (!a[i]) continue;
+        const __m128i ai = _mm_set_epi64x(0, (long long)a[i]);
+        const int jmax = low_only > 0 ? (low_only - i < nb ? low_only - i : nb) : nb;
+        for (int j = 0; j < jmax; ++j) {
+            const __m128i p = _mm_clmulepi64_si128(ai, _mm_set_epi64x(0, (long long)b[j]), 0x00);
+            c[i + j] ^= (uint64_t)_mm_cvtsi128_si64(p);
+            if (i + j + 1 < nc) c[i + j + 1] ^= (uint64_t)_mm_extract_epi64(p, 1);
+        }
+    }
+}
+
+// out[0 .. nout) = a[0 .. na) >> sh bits
+void pshr(const uint64_t* a, int na, int sh, uint64_t* out, int nout) {
+    const int ws = sh >> 6, bs = sh & 63;
+    for (int k = 0; k < nout; ++k) {
+        uint64_t v = (k + ws < na) ? a[k + ws] >> bs : 0;
+        if (bs && k + ws + 1 < na) v |= a[k + ws + 1] << (64 - bs);
+        out[k] = v;
+    }
+}
+
+void init_mu() {                              // long division of x^(2 DEG) by phi, once
+    std::vector<uint64_t> rem(2 * PW + 2, 0);
+    memset(&g_barrett, 0, sizeof g_barrett);
+    const int top = 2 * DEG;
+    rem[top >> 6] |= 1ull << (top & 63);
+    for (int i = top; i >= DEG; --i) {
+        if (!((rem[i >> 6] >> (i & 63)) & 1ull)) continue;
+        const int sh = i - DEG, ws = sh >> 6, bs = sh & 63;
+        pflip(g_barrett, sh);
+        for (int k = 0; k < PW; ++k) {
+            const uint64_t v = g_phi.w[k];
+            rem[k + ws] ^= v << bs;
+            if (bs) rem[k + ws + 1] ^= v >> (64 - bs);
+        }
+    }
+}
+
+void reduce_clmul(const std::vector<uint64_t>& a, Poly& r) {      // a: 2 PW + 2 words, degree < 2 DEG
+    uint64_t a1[PW + 1], t[2 * PW + 2], q[PW + 1], qp[PW + 1];
+    pshr(a.data(), (int)a.size(), DEG, a1, PW + 1);               // floor(a / x^DEG): degree < DEG
+    pmul(a1, PW, g_barrett.w, PW, t);                                    // (a1 has no bits at or above DEG: PW words suffice)
+    t[2 * PW] = t[2 * PW + 1] = 0;
+    pshr(t, 2 * PW + 2, DEG, q, PW + 1);                            // q = floor(a1 mu / x^DEG)
+    pmul(q, PW, g_phi.w, PW, qp, PW);                               // low PW words of q * phi
+    for (int k = 0; k < PW; ++k) r.w[k] = a[k] ^ qp[k];
+    r.w[PW - 1] &= (DEG & 63) ? ((1ull << (DEG & 63)) - 1ull) : ~0ull;      // mod x^DEG (DEG = 311 * 64 + 33)
+}
+#endif
+
 inline uint64_t spread32(uint32_t x) {       // interleave zeros: bit i -> bit 2i
     uint64_t v = x;
     v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
@@ -139,6 +207,13 @@ inline uint64_t spread32(uint32_t x) {       // interleave zeros: bit i -> bit 2
     return v;
 }
 
+#ifdef MAUS_HAVE_CLMUL
+bool use_clmul() { static const bool ok = __builtin_cpu_supports("pclmul"); return ok && g_barrett_ok; }
+#define REDUCE(tmp, r) do { if (use_clmul()) reduce_clmul(tmp, r); else reduce(tmp, r); } while (0)
+#else
+#define REDUCE(tmp, r) reduce(tmp, r)
+#endif
+
 void poly_pow_x(uint64_t J, Poly& out) {      // x^J mod phi, square-and-multiply on the bits of J
     Poly r; memset(&r, 0, sizeof r); r.w[0] = 1;               // 1
     std::vector<uint64_t> tmp(2 * PW + 2);
@@ -147,13 +222,13 @@ void poly_pow_x(uint64_t J, Poly& out) {      // x^J mod phi, square-and-multipl
         // square
         std::fill(tmp.begin(), tmp.end(), 0);
         for (int k = 0; k < PW; ++k) { tmp[2 * k] = spread32((uint32_t)r.w[k]); tmp[2 * k + 1] = spread32((uint32_t)(r.w[k] >> 32)); }
-        reduce(tmp, r);
+        REDUCE(tmp, r);
         if ((J >> b) & 1ull) {                                   // times x
             std::fill(tmp.begin(), tmp.end(), 0);
             uint64_t carry = 0;
             for (int k = 0; k < PW; ++k) { tmp[k] = (r.w[k] << 1) | carry; carry = r.w[k] >> 63; }
             tmp[PW] = carry;
-            reduce(tmp, r);
+            REDUCE(tmp, r);
         }
     }
     out = r;
@@ -187,6 +262,9 @@ int cached_poly(uint64_t J, Poly& g) {
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if (!g_phi_ok) { if (!init_phi()) return -2; g_phi_ok = true; }
+#ifdef MAUS_HAVE_CLMUL
+        if (!g_barrett_ok) { init_mu(); g_barrett_ok = true; }
+#endif
         auto it = g_cache.find(J);
         if (it != g_cache.end()) { g = it->second; return 0; }
     }

@@ -329,7 +329,15 @@ zgemm_kernel(int M, int N, int K,
 //   B image [8 k][32 n]  (512 B per k-row): natural order; the fragment read b = B[k = lane>>4][col = lane&15] is 16
 //       consecutive elements of one row.
 // ---------------------------------------------------------------------------------------
-template <int NST, int MINW, int MB, int NB, bool TILED = false>
+// BLAY = 1 (round 3): B is row-major [n][k] (dot-product form: Y = X A^T, Gram blocks, [V W][W V]^H) and gets the A image's
+// treatment -- [BN rows][8 k], 8 lanes per row, the same source-side swizzle and fragment read.  CONJA / CONJB: the operand's
+// imaginary part enters with the opposite sign, i.e. with a_i' = -Ai (b_i' = -Bi)
+//     Re = Ar Br - a_i' b_i',   Im = (Ar + a_i')(Br + b_i') - Ar Br - a_i' b_i':
+// the third product's operand sums become differences (one VALU op either way) and the epilogue takes P2 = Ai Bi with the sign
+// sa sb; the MFMA stream is unchanged.  With these the population products (A@X of the Rayleigh / residual phases and of every
+// GMRES inner iteration, A^H u of the SVD step, conj(X) V of the Hermitian match) run 6 M N K on the pipe instead of the 4M
+// kernel's 8 M N K (MAUS_POPGEMM_3M=0: back to 4M).
+template <int NST, int MINW, int MB, int NB, bool TILED = false, int BLAY = 0, bool CONJA = false, bool CONJB = false>
 __global__ void __launch_bounds__(256, MINW)
 zgemm3m_dma_kernel(int M, int N, int K,
                    const c128* __restrict__ Ag, long lda, long strideA,
@@ -377,13 +385,20 @@ zgemm3m_dma_kernel(int M, int N, int K,
         const int gm = min(m0 + r, M - 1);
         srcA[j] = A + (long)(a_rows ? a_rows[gm] : gm) * (TILED ? 64 : lda) + kk;
     }
+    static_assert(!(TILED && BLAY), "tiled operands: plain layout only");
     const c128* srcB[B_PW];
     const long ldb_e = TILED ? 64 : ldb;
 #pragma unroll
     for (int j = 0; j < B_PW; ++j) {
-        const int e = (B_PW * wave + j) * 64 + lane;             // element of the [8][BN] image
-        const int gn = min(n0 + (e % BN), N - 1);
-        srcB[j] = B + (long)(e / BN) * ldb_e + (TILED ? tile_off(ldb, tcol.z + gn) + (long)tcol.y * 64 : (long)gn);
+        if (BLAY == 0) {
+            const int e = (B_PW * wave + j) * 64 + lane;             // element of the [8][BN] image
+            const int gn = min(n0 + (e % BN), N - 1);
+            srcB[j] = B + (long)(e / BN) * ldb_e + (TILED ? tile_off(ldb, tcol.z + gn) + (long)tcol.y * 64 : (long)gn);
+        } else {
+            const int r = (B_PW * wave + j) * 8 + (lane >> 3);       // row of the [BN][8] image = column n of the product
+            const int kk = (lane & 7) ^ ((r >> 1) & 7);
+            srcB[j] = B + (long)min(n0 + r, N - 1) * ldb + kk;
+        }
     }
 
     auto issue = [&](int st, int k0) {
@@ -395,7 +410,7 @@ zgemm3m_dma_kernel(int M, int N, int K,
             __builtin_amdgcn_global_load_lds((const void*)(srcA[j] + ta), (__attribute__((address_space(3))) void*)(As + (A_PW * wave + j) * 64), 16, 0, 0);
 #pragma unroll
         for (int j = 0; j < B_PW; ++j)
-            __builtin_amdgcn_global_load_lds((const void*)(srcB[j] + (long)k0 * ldb_e), (__attribute__((address_space(3))) void*)(Bs + (B_PW * wave + j) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(srcB[j] + (BLAY ? (long)k0 : (long)k0 * ldb_e)), (__attribute__((address_space(3))) void*)(Bs + (B_PW * wave + j) * 64), 16, 0, 0);
     };
 
     d4 cre[MB][NB], cim[MB][NB], c3[MB][NB];
@@ -433,16 +448,19 @@ zgemm3m_dma_kernel(int M, int N, int K,
                 fa[ks][i] = As[r * BKS + (k ^ ((r >> 1) & 7))];
             }
 #pragma unroll
-            for (int j = 0; j < NB; ++j) fb[ks][j] = Bs[k * BN + bcol0 + j * 16];
+            for (int j = 0; j < NB; ++j) {
+                const int cn = bcol0 + j * 16;
+                fb[ks][j] = BLAY ? Bs[cn * BKS + (k ^ ((cn >> 1) & 7))] : Bs[k * BN + cn];
+            }
         }
         if (t + NST - 1 < nst) issue((t + NST - 1) % NST, (t + NST - 1) * BKS);     // into the buffer stage t-1 used
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             double as[MB], bs[NB];
 #pragma unroll
-            for (int i = 0; i < MB; ++i) as[i] = fa[ks][i].x + fa[ks][i].y;
+            for (int i = 0; i < MB; ++i) as[i] = CONJA ? fa[ks][i].x - fa[ks][i].y : fa[ks][i].x + fa[ks][i].y;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) bs[j] = fb[ks][j].x + fb[ks][j].y;
+            for (int j = 0; j < NB; ++j) bs[j] = CONJB ? fb[ks][j].x - fb[ks][j].y : fb[ks][j].x + fb[ks][j].y;
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -453,6 +471,7 @@ zgemm3m_dma_kernel(int M, int N, int K,
                 }
         }
     }
+    constexpr double S2 = (CONJA != CONJB) ? -1.0 : 1.0;       // sign of P2 = Ai Bi in the result (sa sb)
 
     // epilogue (as in zgemm_kernel)
 #pragma unroll
@@ -475,15 +494,15 @@ zgemm3m_dma_kernel(int M, int N, int K,
             for (int r = 0; r < 4; ++r) {
                 const int gm = m0 + wm * 16 * MB + i * 16 + (lane >> 4) + 4 * r;
                 if (gm < M && gn < N) {
-                    const double vr = cre[i][j][r] - cim[i][j][r];
-                    const double vi = (c3[i][j][r] - cre[i][j][r]) - cim[i][j][r];
+                    const double vr = cre[i][j][r] - S2 * cim[i][j][r];
+                    const double vi = (c3[i][j][r] - cre[i][j][r]) - S2 * cim[i][j][r];
                     C[off[r]] = cmake(alpha * vr + cold[r].x, alpha * vi + cold[r].y);
                 }
             }
         }
 }
 
-template <int NST, int MINW, int MB, int NB, bool TILED = false>
+template <int NST, int MINW, int MB, int NB, bool TILED = false, int BLAY = 0, bool CONJA = false, bool CONJB = false>
 void launch_dma(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA, const c128* B, long ldb, long sB,
                 c128* C, long ldc, long sC, double alpha, int beta, int batch, int, bool, bool,
                 const int* a_rows, const int* c_rows, long rows_stride, TCol tcol = TCol{0, 0, 0})
@@ -491,8 +510,19 @@ void launch_dma(hipStream_t st, int M, int N, int K, const c128* A, long lda, lo
     constexpr int BM = 32 * MB, BN = 32 * NB;
     int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     int nwg = tiles_m * tiles_n;
-    hipLaunchKernelGGL((zgemm3m_dma_kernel<NST, MINW, MB, NB, TILED>), dim3(nwg, batch), dim3(256), 0, st,
+    hipLaunchKernelGGL((zgemm3m_dma_kernel<NST, MINW, MB, NB, TILED, BLAY, CONJA, CONJB>), dim3(nwg, batch), dim3(256), 0, st,
                        M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, tiles_n, nwg, a_rows, c_rows, rows_stride, tcol);
+}
+
+// population products (dot-product layout and / or conjugated operands) on the DMA-staged 3M kernel: 64 x 64 tiles for large
+// products, 64 x 32 otherwise
+template <int BLAY, bool CONJA, bool CONJB>
+void launch_dma_pop(hipStream_t st, int M, int N, int K, const c128* A, long lda, long sA, const c128* B, long ldb, long sB,
+                    c128* C, long ldc, long sC, double alpha, int beta, int batch, int blay, bool conja, bool conjb,
+                    const int* a_rows, const int* c_rows, long rows_stride)
+{
+    if (M >= 1536 && N >= 1536) launch_dma<2, 3, 2, 2, false, BLAY, CONJA, CONJB>(st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, batch, blay, conja, conjb, a_rows, c_rows, rows_stride);
+    else launch_dma<2, 5, 2, 1, false, BLAY, CONJA, CONJB>(st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, batch, blay, conja, conjb, a_rows, c_rows, rows_stride);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool PIPE, int MINW>
@@ -589,6 +619,16 @@ void maus_zgemm_launch_rows(hipStream_t st, int M, int N, int K, const c128* A, 
         }
         if (N <= 32) { launch_lu_only<128, 32, 16, 4, 1, false, 2>(ARGS); return; }
         if (M <= 32) { launch_lu_only<32, 128, 16, 1, 4, false, 2>(ARGS); return; }
+    }
+    // Population products with a dot-product B layout and / or conjugated operands: the DMA-staged 3M kernel (round 3) where
+    // its staging applies (K a multiple of 8, >= 64, more than one 32-row tile); MAUS_POPGEMM_3M=0: the 4M kernel below
+    static const int pop3m = [] { const char* e = getenv("MAUS_POPGEMM_3M"); return e ? atoi(e) : 1; }();
+    if (pop3m && use3m && cfg == 0 && (blay != 0 || conja || conjb) && M > 32 && (K % 8) == 0 && K >= 64) {
+        if (blay == 1 && !conja && !conjb) { launch_dma_pop<1, false, false>(ARGS); return; }
+        if (blay == 1 && conja && !conjb) { launch_dma_pop<1, true, false>(ARGS); return; }
+        if (blay == 1 && !conja && conjb) { launch_dma_pop<1, false, true>(ARGS); return; }
+        if (blay == 0 && conja && !conjb) { launch_dma_pop<0, true, false>(ARGS); return; }
+        if (blay == 0 && !conja && conjb) { launch_dma_pop<0, false, true>(ARGS); return; }
     }
     // 4M (population matvecs, Hermitian / SVD products, MAUS_GEMM_3M=0): 64x64 tiles, 32x32 wave tile.
     // With the next K-tile genuinely in flight during the MFMAs this needs ~160 VGPRs: three workgroups per CU.

@@ -113,7 +113,7 @@ def self_launch(args) -> int:
 # ---------------------------------------------------------------------------------------------------------------------
 OTHER = {
     "c2": dict(n=1024, pop=256, steps=10, kind="eig", what="1024x1024 dense non-Hermitian eig (complex128 Ginibre/sqrt(n)), direct-LU path"),
-    "c3": dict(n=4096, pop=512, steps=4, kind="lin", what="4096x4096 linear system diag(10^U(0,7) e^{2 pi i U}) + 0.1 Ginibre/sqrt(n) (cond ~1e7, "
+    "c3": dict(n=4096, pop=512, steps=12, kind="lin", what="4096x4096 linear system diag(10^U(0,7) e^{2 pi i U}) + 0.1 Ginibre/sqrt(n) (cond ~1e7, "
                                                           "'Fragile': GMRES preferred), stuck_counter = 2 preset before every step so that the "
                                                           "Jacobi preconditioner is active (AMS:65-72)"),
     "c4": dict(n=8192, pop=128, steps=3, kind="herm", what="8192x8192 Hermitian eig (B+B^H)/2, Hermitian shortcut (AMS:155-181), one GPU's share "
@@ -255,10 +255,12 @@ def run_other_config(args):
         dom = "zgemm" if prof["zgemm"]["ms"] >= 0.25 * tot_ms else dom
     d = prof[dom]
     if dom in gemm_classes:
-        use3m = kind == "eig" and os.environ.get("MAUS_GEMM_3M", "1") != "0"      # population GEMMs run the 4M kernel
+        # LU trailing updates and (since round 3) the population products run the 3M kernel: 6 M N K executed per complex GEMM
+        use3m = os.environ.get("MAUS_GEMM_3M", "1") != "0" and (kind == "eig" or os.environ.get("MAUS_POPGEMM_3M", "1") != "0")
         exec_ratio = 0.75 if use3m else 1.0
         alg = d["flops"] / max(1e-12, d["ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": f"{dom} ({'3M LU trailing-update zgemm' if use3m else '4M population zgemm: A@X / A^H U / conj(X) V'}, v_mfma_f64_16x16x4_f64)",
+        what = "3M LU trailing-update zgemm" if kind == "eig" else f"{'3M' if use3m else '4M'} population zgemm: A@X / A^H U / conj(X) V"
+        roof = {"bound": "mfma", "kernel": f"{dom} ({what}, v_mfma_f64_16x16x4_f64)",
                 "achieved": alg * exec_ratio, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg * exec_ratio / FP64_MFMA_PEAK_TFLOPS,
                 "achieved_algorithmic_8mnk": alg, "launches": d["launches"], "avg_launch_ms": d["ms"] / max(1, d["launches"]),
                 "traffic": None, "kernel_time_share": d["ms"] / tot_ms if tot_ms > 0 else None,
