@@ -34,9 +34,9 @@ int ensure_scalars(maus_ctx* c, int count) {
 
 int ensure_scratch(maus_ctx* c, size_t bytes) {
     if (bytes <= c->scratch_bytes) return 0;
-    // grow by at least a quarter: the population -- and with it the GMRES scratch -- grows by up to 15 candidates per iteration
+    // a quarter of headroom, and growth by at least a quarter: the population -- and with it the GMRES scratch -- grows by up to 15 candidates per iteration
     // (AMS:533-534), and an exact fit would free and map hundreds of MB in every loop body
-    size_t want = std::max(bytes, c->scratch_bytes + c->scratch_bytes / 4);
+    size_t want = std::max(bytes + bytes / 4, c->scratch_bytes + c->scratch_bytes / 4);
     if (c->scratch) { (void)hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
     if (hipMalloc(&c->scratch, want) != hipSuccess) { (void)hipGetLastError(); want = bytes; HIPCHK(c, hipMalloc(&c->scratch, want)); }
     c->scratch_bytes = want;

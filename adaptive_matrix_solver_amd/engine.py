@@ -695,7 +695,11 @@ class DeviceEngine:
         # step (freeing and mapping ~100 GB takes seconds; HBM is otherwise idle)
         world = self.comm.world if self.comm is not None else 1
         share = -(-len(cands) // world)
-        self.ctx.lu_reserve(n, max(2 * share, share + -(-320 // world)))
+        if pref == DIRECT or self.gmres_compat == "scipy-legacy":
+            self.ctx.lu_reserve(n, max(2 * share, share + -(-320 // world)))
+        # (GMRES preferred: the LU only serves the candidates whose GMRES attempt fails, and its workspace is sized for them
+        # when that happens -- reserving the whole population's H_k here cost configs[2] 4.7 s in its first loop body and a
+        # second 270 GB allocation in the next one, for a workspace the step never touched)
 
         i = 0
         while i < len(cands):
