@@ -658,6 +658,8 @@ void maus_zgemm_launch_lu(hipStream_t st, int M, int N, int K, const c128* H, co
     if (N <= 16) { launch_lu_only<128, 16, 16, 4, 1, false, 4, false, true>(ARGS); return; }
     if (M <= 16) { launch_lu_only<16, 128, 16, 1, 4, false, 3, false, true>(ARGS); return; }
     if (M > 32 && (K % 8) == 0 && K >= dma_kmin) {
+        // (round 3: 64 x 64 tiles from M >= 1024 / 512 and N >= 128 / 256 / 1024, or only from 2048: the 181-solve sweep stays
+        // within 0.5 ms of 494 ms -- the K = 128 / 256 levels are not bound by the tile shape)
         if (M >= 1536 && N >= 1536) launch_dma<2, 3, 2, 2, true>(ARGS);      // 64 x 64 tiles, three workgroups per CU
         else launch_dma<2, 5, 2, 1, true>(ARGS);
         return;
