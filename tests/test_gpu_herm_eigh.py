@@ -154,3 +154,35 @@ def test_reporting_prologue_through_the_device_reduction():
     # ... and the engine's own matrix / population are untouched by the scratch context
     s.loop_body(1)
     s.engine.ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["identity", "zero", "projector", "rank1", "scaled_small", "scaled_large", "real_symmetric"])
+def test_degenerate_and_scaled_inputs(ctx, kind):
+    """Repeated eigenvalues (the eigenvectors are then any orthonormal basis of the eigenspaces: checked through the
+    decomposition itself), a zero matrix, badly scaled entries, a real symmetric matrix."""
+    n = 96
+    rng = np.random.default_rng(11)
+    Q = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))[0]
+    if kind == "identity":
+        A = np.eye(n, dtype=np.complex128) * 2.5
+    elif kind == "zero":
+        A = np.zeros((n, n), dtype=np.complex128)
+    elif kind == "projector":
+        A = Q[:, :30] @ Q[:, :30].conj().T
+    elif kind == "rank1":
+        A = 3.0 * np.outer(Q[:, 0], Q[:, 0].conj())
+    elif kind == "scaled_small":
+        A = scenarios.hermitian(n, 3) * 1e-120
+    elif kind == "scaled_large":
+        A = scenarios.hermitian(n, 3) * 1e+120
+    else:
+        B = rng.standard_normal((n, n))
+        A = ((B + B.T) / 2).astype(np.complex128)
+    A = (A + A.conj().T) / 2
+    d, e, w, V = _device_eigh(ctx, A)
+    scale = max(np.abs(A).max(), 1e-300)
+    assert np.all(np.isfinite(w)) and np.all(np.isfinite(V))
+    assert np.abs(w - sla.eigvalsh(A)).max() <= 1e-12 * scale * n
+    assert np.linalg.norm(A @ V - V * w[None, :]) <= 1e-12 * scale * n
+    assert np.linalg.norm(V.conj().T @ V - np.eye(n)) <= 1e-12 * n
+    assert np.abs(V[0].imag).max() == 0.0
