@@ -276,7 +276,7 @@ class DeviceEngine:
             iv = self.ctx.hist_append(POP_X, slots, lv)
             iu = self.ctx.hist_append(POP_U, slots, lazy[0].M_rows) if svd else None
             gen = self.ctx.hist_generation() if hasattr(self.ctx, "hist_generation") else 0      # once per step, not per candidate
-            # flat tuples of ints: solver.history_ref() without the tag and the scalar (SolutionCandidate._record_history adds them)
+            # flat tuples of ints: the compact history reference without its tag and scalar (SolutionCandidate._record_history adds them)
             if svd:
                 lu = lazy[0].M_rows
                 for k, c in enumerate(lazy):

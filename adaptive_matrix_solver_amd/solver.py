@@ -204,14 +204,11 @@ class _HistRef:
 _HREF = "\x00maus-history-row"        # first item of a compact history reference (see _LazyHistory)
 
 
-def history_ref(scalar, gen, rows):
-    """Compact form of a _HistRef inside param_history: an exact tuple of atoms (tag, scalar, store generation, index, length
-    [, index, length]).  The cyclic garbage collector stops tracking such a tuple at its first pass, whereas one _HistRef
-    instance per candidate and step stays tracked for good: at 6 144 candidates (BASELINE configs[4]) that was half a million
-    tracked objects after 20 loop bodies and a full collection of 12-33 ms every third body (tools/gc_probe.py)."""
-    return (_HREF, scalar, gen) + tuple(rows)
-
-
+# A recorded iterate whose vectors live in the device history store is kept in param_history as an exact tuple of atoms
+#     (_HREF, scalar, store generation, index, length [, index, length])
+# -- the compact form of a _HistRef.  The cyclic garbage collector stops tracking such a tuple at its first pass, whereas one
+# _HistRef instance per candidate and step stays tracked for good: at 6 144 candidates (BASELINE configs[4]) that was half a
+# million tracked objects after 20 loop bodies and a full collection of 12-33 ms every third body (tools/gc_probe.py).
 def is_history_ref(entry) -> bool:
     return type(entry) is tuple and len(entry) >= 5 and entry[0] is _HREF
 
