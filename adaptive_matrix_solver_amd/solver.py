@@ -568,6 +568,17 @@ class MAUS_Solver:
                         diag_info["condition_number_from_eigh"] = True
                     except np.linalg.LinAlgError:
                         cond_num_val = None
+                if (cond_num_val is None and getattr(self, "_cond_device", None) is not None and matrix.shape[0] > self._cond_exact_max
+                        and self.engine.use_device_eigh(2 * matrix.shape[0]) and np.all(np.isfinite(matrix))):
+                    # the estimate fell into the guard band of a threshold: np.linalg.cond's own definition, sigma_max / sigma_min,
+                    # with the singular values from the device (a host SVD of a 4096 x 4096 matrix is ~20 s of the start-up)
+                    from .engine import singular_values_device
+                    sv = singular_values_device(matrix, self._cond_device)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        cond_num_val = np.float64(sv[0]) / np.float64(sv[-1])
+                    if np.isnan(cond_num_val):
+                        cond_num_val = np.float64(np.inf)
+                    diag_info["condition_number_from_device_svd"] = True
                 if cond_num_val is None:
                     cond_num_val = np.linalg.cond(matrix)
                 if np.isinf(cond_num_val) or cond_num_val > 1e15:
@@ -899,18 +910,8 @@ class MAUS_Solver:
                 # singular values as the positive eigenvalues of the Hermitian embedding [[0, M], [M^H, 0]] (+-sigma_i and
                 # |rows - cols| zeros), reduced to tridiagonal form on the device: the same absolute accuracy eps ||M|| as
                 # LAPACK's bidiagonal SVD, without its O(n^3) on the host
-                r, c = self.N_rows, self.N_cols
-                Hm = np.zeros((r + c, r + c), dtype=np.complex128)
-                Hm[:r, r:] = self.M
-                Hm[r:, :r] = self.M.conj().T
-                cH = _cabi.Context(self.engine.ctx.device)
-                try:
-                    cH.set_matrix(Hm)
-                    d, e = cH.herm_tridiag()
-                finally:
-                    cH.close()
-                w = sla.eigvalsh_tridiagonal(d, e)
-                return np.maximum(np.sort(w)[::-1][: min(r, c)], 0.0).tolist()
+                from .engine import singular_values_device
+                return singular_values_device(self.M, self.engine.ctx.device).tolist()
             return sorted(sla.svd(self.M, compute_uv=False).tolist(), reverse=True)
         except (np.linalg.LinAlgError, ValueError) as e:
             print(f"NumPy reference calculation failed: {e}.")

@@ -48,7 +48,19 @@ def test_solver_decisions_unchanged(name):
         assert fast.problem_knowledge[key] == exact.problem_knowledge[key], key
     assert fast.strat_params == exact.strat_params
     if not expect_trusted:
-        assert fast.cond_number == exact.cond_number        # the exact value was computed after all
+        # the exact value was computed after all: np.linalg.cond's sigma_max / sigma_min with the singular values from the
+        # device tridiagonalisation (same absolute accuracy eps ||A|| in sigma_min as LAPACK's SVD, i.e. eps * cond relative)
+        assert fast.diag_info.get("condition_number_from_device_svd") is True
+        assert abs(fast.cond_number - exact.cond_number) <= 1e-7 * exact.cond_number
+
+
+def test_singular_values_on_the_device_against_lapack():
+    import scipy.linalg as sla
+    from adaptive_matrix_solver_amd.engine import singular_values_device
+    for A in (scenarios.prescribed_svd(300, 220, 4, -7.0), scenarios.ginibre(257, 3), np.zeros((40, 40), dtype=np.complex128)):
+        sv = singular_values_device(A, 0)
+        ref = sla.svd(A, compute_uv=False)
+        assert sv.shape == ref.shape and np.abs(sv - ref).max() <= 1e-13 * max(ref[0], 1e-300) * max(A.shape)
 
 
 def test_hermitian_guard_band_takes_the_condition_number_from_eigh(monkeypatch):
