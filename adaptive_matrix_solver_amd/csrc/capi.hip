@@ -526,22 +526,32 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
         HIPCHK(c, hipMalloc((void**)&mb.base, sizeof(uint32_t) * 624));
         mb.cap = cap;
     }
-    struct DevLevel { size_t off; int count; const int* taps; int ntap16; int src_off; };
+    struct DevLevel { size_t off; int count; MausJumpPolys P; int src_off; bool multi; };
     std::vector<DevLevel> levels;
-    for (const MausMtPlan::Level& L : pl.levels) {
-        auto it = c->mt_taps.find(L.J);
-        if (it == c->mt_taps.end()) {                       // tap list of x^J mod phi, cached on the device
+    auto poly_taps = [&](uint64_t J, const int** taps_out, int* ntap16_out) -> int {     // tap list of x^J mod phi, cached on the device
+        auto it = c->mt_taps.find(J);
+        if (it == c->mt_taps.end()) {
             std::vector<uint64_t> poly(312);
-            if (maus_mt_jump_poly(L.J, poly.data())) FAIL(c, "MT19937 jump polynomial failed");
+            if (maus_mt_jump_poly(J, poly.data())) FAIL(c, "MT19937 jump polynomial failed");
             std::vector<int> taps;
             for (int i = 0; i < 19937; ++i) if ((poly[i >> 6] >> (i & 63)) & 1ull) taps.push_back(i);
             while (taps.size() % 16) taps.push_back(maus_mt_zero_tap());
             int* dt = nullptr;
             HIPCHK(c, hipMalloc((void**)&dt, sizeof(int) * taps.size()));
             HIPCHK(c, hipMemcpy(dt, taps.data(), sizeof(int) * taps.size(), hipMemcpyHostToDevice));
-            it = c->mt_taps.emplace(L.J, std::make_pair(dt, (int)(taps.size() / 16))).first;
+            it = c->mt_taps.emplace(J, std::make_pair(dt, (int)(taps.size() / 16))).first;
         }
-        levels.push_back({L.off, L.count, it->second.first, it->second.second, L.src_off});
+        *taps_out = it->second.first; *ntap16_out = it->second.second;
+        return 0;
+    };
+    for (const MausMtPlan::Level& L : pl.levels) {
+        DevLevel D{L.off, L.count, {}, L.src_off, L.multi};
+        memset(&D.P, 0, sizeof D.P);
+        bool need[16] = {false};
+        if (L.multi) for (int i = 0; i < L.count; ++i) need[pl.hs[L.off + L.count + i] & 15] = true;
+        else need[1] = true;
+        for (int v = 1; v < 16; ++v) if (need[v] && poly_taps((uint64_t)v * L.J, &D.P.taps[v], &D.P.ntap16[v])) return -1;
+        levels.push_back(D);
     }
     const std::vector<int>& hs = pl.hs;
     if (hs.size() > mb.int_cap) {
@@ -554,7 +564,7 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
     HIPCHK(c, hipMemcpyAsync(mb.ints, hs.data(), sizeof(int) * hs.size(), hipMemcpyHostToDevice, w.st));
     HIPCHK(c, hipStreamSynchronize(w.st));                       // staging (hs, d->key) is reusable from here on
     maus_mt_copy_states(w.st, mb.states, mb.base, ngen);
-    for (const DevLevel& L : levels) maus_mt_jump(w.st, mb.states, mb.ints + L.off, L.count, L.taps, L.ntap16, L.src_off);
+    for (const DevLevel& L : levels) maus_mt_jump(w.st, mb.states, mb.ints + L.off, L.multi ? mb.ints + L.off + L.count : nullptr, L.count, L.P, L.src_off);
     const int* d_extra = mb.ints; const int* d_rpos = mb.ints + ngen;
     prof_tick(c, KC_BUILD, 0, 0, 0);
     maus_build_h_mt(w.st, c->A, n, w.npad, w.ldh, w.strideH, w.H, g, pl.S, (long)pl.E, c->d_c1 + lo, c->d_r1 + lo, rhs_mode, c->X, c->ldp,

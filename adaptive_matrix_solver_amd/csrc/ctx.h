@@ -18,7 +18,8 @@ void maus_load_h(const LuWs& w, const c128* d_Ain, const c128* d_bin);
 int maus_lu_max_npad();
 size_t maus_lu_mw_sync_bytes();
 void maus_mt_copy_states(hipStream_t st, uint32_t* states, const uint32_t* base, int count);
-void maus_mt_jump(hipStream_t st, uint32_t* states, const int* sel, int nsel, const int* taps, int ntap16, int src_off);
+#include "mtjump.h"
+void maus_mt_jump(hipStream_t st, uint32_t* states, const int* sel, const int* mult, int nsel, const MausJumpPolys& P, int src_off);
 int maus_mt_zero_tap();
 void maus_build_h_mt(hipStream_t st, const c128* A, int n, int npad, long ldh, long strideH, c128* H, int G, int S, long E,
                      const c128* d_shift, const double* d_psi, int rhs_mode, const c128* X, long ldx, const int* d_slots,

@@ -14,6 +14,7 @@
 //     H = (A - lambda*delta) + (psi*delta + ((u-.5)*psi)*0.15) with NumPy's rounding order.
 #include "common.h"
 #include "luws.h"
+#include "mtjump.h"
 #include <cstdint>
 #include <cstdlib>
 
@@ -62,10 +63,13 @@ constexpr int JT = 640;                                  // one output word per 
 constexpr int XS_WORDS = CONV_BLOCKS * MTN;              // 20592
 constexpr int ZTAP = XS_WORDS;                           // xs[ZTAP .. ZTAP+JT) == 0
 __global__ void __launch_bounds__(JT)
-mt_jump_kernel(uint32_t* states, const int* __restrict__ sel, const int* __restrict__ taps, int ntap16, int src_off)
+mt_jump_kernel(uint32_t* states, const int* __restrict__ sel, const int* __restrict__ mult, MausJumpPolys P, int src_off)
 {
     __shared__ uint32_t xs[XS_WORDS + JT];
     const int tid = threadIdx.x;
+    const int v = mult ? mult[blockIdx.x] : 1;             // which polynomial of the launch: x^(v J)  (workgroup-uniform)
+    const int* __restrict__ taps = P.taps[v];
+    const int ntap16 = P.ntap16[v];
     uint32_t* S = states + (long)sel[blockIdx.x] * MTN;
     const uint32_t* Src = S - (long)src_off * MTN;
     for (int k = tid; k < MTN; k += JT) xs[k] = Src[k];
@@ -280,8 +284,8 @@ void maus_mt_copy_states(hipStream_t st, uint32_t* states, const uint32_t* base,
     hipLaunchKernelGGL(mt_copy_state_kernel, dim3(count), dim3(256), 0, st, states, base, count);
 }
 int maus_mt_zero_tap() { return ZTAP; }
-void maus_mt_jump(hipStream_t st, uint32_t* states, const int* sel, int nsel, const int* taps, int ntap16, int src_off) {
-    if (nsel > 0) hipLaunchKernelGGL(mt_jump_kernel, dim3(nsel), dim3(JT), 0, st, states, sel, taps, ntap16, src_off);
+void maus_mt_jump(hipStream_t st, uint32_t* states, const int* sel, const int* mult, int nsel, const MausJumpPolys& P, int src_off) {
+    if (nsel > 0) hipLaunchKernelGGL(mt_jump_kernel, dim3(nsel), dim3(JT), 0, st, states, sel, mult, P, src_off);
 }
 void maus_build_h_mt(hipStream_t st, const c128* A, int n, int npad, long ldh, long strideH, c128* H, int G, int S, long E,
                      const c128* d_shift, const double* d_psi, int rhs_mode, const c128* X, long ldx, const int* d_slots,

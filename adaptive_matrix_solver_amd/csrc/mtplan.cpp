@@ -4,8 +4,8 @@
 //     t = pos + (draw index mm) * 2N^2 + 2 * sb * E,         mm = (lead + ord_k * wpc) / 2N^2 + part,
 // i.e. in block q = t / 624 at position t % 624.  q is reached as  m * dj + b * dj2  blocks by jump polynomials plus
 // `extra` real block regenerations inside the build kernel:
-//   * over the draw index m by binary lifting (level i applies x^(624 * dj * 2^i) to the states whose m has bit i set), on
-//     the first sub-stream of every draw only;
+//   * over the draw index m by lifting in base 16 (level i applies x^(v * 624 * dj * 16^i) to the states whose m has the
+//     hexadecimal digit v at position i), on the first sub-stream of every draw only;
 //   * over the sub-stream index b by a doubling tree: level i computes the states with b in [2^i, 2^(i+1)) from the
 //     states with b - 2^i (one jump per generator; lifting every sub-stream on its own cost popcount(m) + popcount(b)
 //     jumps each, 13 launches of ~2900 jump workgroups = 22 ms at 181 candidates x 16 sub-streams).
@@ -59,19 +59,27 @@ int maus_mt_plan(const maus_mt_desc* d, int n, int first, int g, int s_override,
             }
     }
     out->levels.clear();
-    // lifting over m: on the first sub-stream of each draw when the tree below derives the others from it, else on all
-    for (int bit = 0; dj && bit < 64 && (maxm >> bit); ++bit) {
+    // lifting over m, one HEXADECIMAL digit per level (a launch applies x^(v J) with the generator's own digit v: three
+    // dependent launches for m < 4096 where binary lifting needed twelve, each ~0.2-0.35 ms whatever it carries): on the first
+    // sub-stream of each draw when the tree below derives the others from it, else on all
+    for (int dig = 0; dj && 4 * dig < 64 && (maxm >> (4 * dig)); ++dig) {
         const size_t off = hs.size();
-        for (int i = 0; i < ngen; ++i) if (((m[i] >> bit) & 1ull) && (!dj2 || (i / 2) % S == 0)) hs.push_back(i);
-        const int cnt = (int)(hs.size() - off);
-        if (cnt) out->levels.push_back({off, cnt, 624ull * dj * (1ull << bit), 0});
+        std::vector<int> mult;
+        for (int i = 0; i < ngen; ++i) {
+            const int v = (int)((m[i] >> (4 * dig)) & 15ull);
+            if (v && (!dj2 || (i / 2) % S == 0)) { hs.push_back(i); mult.push_back(v); }
+        }
+        const int cnt = (int)mult.size();
+        hs.insert(hs.end(), mult.begin(), mult.end());
+        if (cnt) out->levels.push_back({off, cnt, 624ull * dj << (4 * dig), 0, true});
+        else hs.resize(off);
     }
     // doubling tree over the sub-stream index: state(b) = x^(624 * dj2 * 2^i) state(b - 2^i) for 2^i <= b < 2^(i+1)
     for (int bit = 0; dj2 && (1 << bit) < S; ++bit) {
         const size_t off = hs.size();
         for (int i = 0; i < ngen; ++i) { const int sb = (i / 2) % S; if (sb >= (1 << bit) && sb < (2 << bit)) hs.push_back(i); }
         const int cnt = (int)(hs.size() - off);
-        if (cnt) out->levels.push_back({off, cnt, 624ull * dj2 * (1ull << bit), 2 << bit});
+        if (cnt) out->levels.push_back({off, cnt, 624ull * dj2 * (1ull << bit), 2 << bit, false});
     }
     (void)maxb;
     out->S = S; out->E = E; out->ngen = ngen; out->dj = dj; out->dj2 = dj2;

@@ -15,8 +15,9 @@ struct MausMtPlan {
     // staging image for the device: extra[ngen] (real block regenerations after the jumps) | rpos[ngen] (position in the
     // block) | the selection list of every lifting level
     std::vector<int> hs;
-    // states[hs[off + i]] <- x^J applied to states[hs[off + i] - src_off]   (src_off = 0: in place)
-    struct Level { size_t off; int count; uint64_t J; int src_off; };
+    // states[hs[off + i]] <- x^(mult_i * J) applied to states[hs[off + i] - src_off]   (src_off = 0: in place).
+    // multi: hs[off + count + i] = mult_i in 1..15 (one hexadecimal digit of the draw index per level); else mult_i = 1
+    struct Level { size_t off; int count; uint64_t J; int src_off; bool multi; };
     std::vector<Level> levels;
 };
 

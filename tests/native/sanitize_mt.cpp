@@ -65,10 +65,12 @@ int main() {
         std::vector<uint64_t> jumped(pl.ngen, 0);
         for (const auto& L : pl.levels) {
             check(L.J % 624 == 0 && L.off + (size_t)L.count <= pl.hs.size(), "plan: level bounds");
+            check(L.off + (size_t)L.count * (L.multi ? 2 : 1) <= pl.hs.size(), "plan: level bounds (multipliers)");
             for (int i = 0; i < L.count; ++i) {
                 const int gi = pl.hs[L.off + i];
-                check(gi >= 0 && gi < pl.ngen && gi - L.src_off >= 0, "plan: generator index out of range");
-                if (gi >= 0 && gi < pl.ngen && gi - L.src_off >= 0) jumped[gi] = jumped[gi - L.src_off] + L.J / 624;
+                const int mult = L.multi ? pl.hs[L.off + L.count + i] : 1;
+                check(gi >= 0 && gi < pl.ngen && gi - L.src_off >= 0 && mult >= 1 && mult <= 15, "plan: generator index / multiplier out of range");
+                if (gi >= 0 && gi < pl.ngen && gi - L.src_off >= 0) jumped[gi] = jumped[gi - L.src_off] + (uint64_t)mult * (L.J / 624);
             }
         }
         for (int k = 0; k < c.g; ++k)
