@@ -215,6 +215,13 @@ int maus_pop_reserve(maus_ctx* c, int capacity) {
         *p = nw;
     }
     c->cap = newcap; c->ldp = ld;
+    // First-use costs of the read-back paths belong here, not in the loop body in which the first candidates converge: the
+    // runtime loads its strided-copy kernel at the first hipMemcpy2D (8 ms measured), and the gather scratch of maus_pop_get /
+    // maus_gram would otherwise be (re)allocated there.
+    if (ensure_scratch(c, sizeof(c128) * (size_t)std::min(newcap, 256) * ld)) return -1;
+    { std::vector<c128> tmp(2 * 8);
+      HIPCHK(c, hipMemcpy2DAsync(tmp.data(), sizeof(c128) * 8, c->X, sizeof(c128) * ld, sizeof(c128) * std::min<long>(8, ld), std::min(2, newcap), hipMemcpyDeviceToHost, c->st));
+      HIPCHK(c, hipStreamSynchronize(c->st)); }
     return 0;
 }
 
@@ -244,17 +251,32 @@ int maus_pop_put(maus_ctx* c, int which, const int* slots, int count, const doub
     return 0;
 }
 
+// rows `slots` of a population array, packed (maus_pop_get, maus_gram)
+__global__ void gather_rows_kernel(const c128* __restrict__ X, long ldx, const int* __restrict__ slots, int len,
+                                   c128* __restrict__ out) {
+    const c128* src = X + (long)slots[blockIdx.x] * ldx;
+    c128* dst = out + (long)blockIdx.x * len;
+    for (int k = threadIdx.x; k < len; k += blockDim.x) dst[k] = src[k];
+}
+
 int maus_pop_get(maus_ctx* c, int which, const int* slots, int count, double* host, int len) {
     c128* P = pop_array(c, which);
     if (!P) FAIL(c, "maus_pop_get: population not reserved / bad array id");
     if (len <= 0 || len > c->ldp) FAIL(c, "maus_pop_get: bad vector length");
     if (check_slots(c, slots, count)) return -1;
     if (count == 0) return 0;
-    if (contiguous(slots, count)) {
+    if (count == 1) {
+        HIPCHK(c, hipMemcpyAsync(host, P + (long)slots[0] * c->ldp, sizeof(c128) * len, hipMemcpyDeviceToHost, c->st));
+    } else if (contiguous(slots, count)) {
         HIPCHK(c, hipMemcpy2DAsync(host, sizeof(c128) * len, P + (long)slots[0] * c->ldp, sizeof(c128) * c->ldp, sizeof(c128) * len, count, hipMemcpyDeviceToHost, c->st));
-    } else {
+    } else if (count < 4) {
         for (int i = 0; i < count; ++i)
             HIPCHK(c, hipMemcpyAsync(host + 2 * (size_t)i * len, P + (long)slots[i] * c->ldp, sizeof(c128) * len, hipMemcpyDeviceToHost, c->st));
+    } else {                                                        // scattered rows: gather on the device, one copy
+        if (upload_slots(c, slots, count)) return -1;
+        if (ensure_scratch(c, sizeof(c128) * (size_t)count * len)) return -1;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(count), dim3(256), 0, c->st, P, c->ldp, c->d_slots, len, (c128*)c->scratch);
+        HIPCHK(c, hipMemcpyAsync(host, c->scratch, sizeof(c128) * (size_t)count * len, hipMemcpyDeviceToHost, c->st));
     }
     HIPCHK(c, hipStreamSynchronize(c->st));
     return 0;
@@ -457,8 +479,18 @@ static LuWs make_ws(maus_ctx* c, int n, int G) {
     return w;
 }
 
-// one stream unless MAUS_LU_STREAMS asks for sub-batches, each at least MAUS_LU_MIN_SUB (64) matrices (see maus_shifted_lu_solve)
-static int lu_stream_count() { const char* e = getenv("MAUS_LU_STREAMS"); int v = e ? atoi(e) : 1; return std::max(1, std::min(8, v)); }
+// Sub-batches on their own streams, each at least MAUS_LU_MIN_SUB (64) matrices (see maus_shifted_lu_solve): MAUS_LU_STREAMS if set;
+// otherwise one stream, except two for more matrices than CUs at n <= 1024 -- there the register-resident panel, the triangular
+// solves and the back-substitution run one workgroup per matrix on a whole CU, so 271 matrices mean a second, nearly empty round
+// of every such launch (n = 1024: 256 -> 271 matrices cost 27.8 -> 32.2 ms), and two halves of <= 256 side by side do not
+// (29.2 ms; BASELINE configs[1] 9 202 -> 9 647 candidate-steps/s, profiles/r03_streams_c2.txt).  At n = 4096 the halves lose
+// more on the zgemm than the tail costs (2 %).
+static int lu_stream_count(int G, int npad) {
+    const char* e = getenv("MAUS_LU_STREAMS");                       // read per call: tests switch it within one process
+    if (e && atoi(e) > 0) return std::min(8, atoi(e));
+    static const int ncu = [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+    return (G > ncu && npad <= 1024) ? 2 : 1;
+}
 
 static int ensure_lu_streams(maus_ctx* c, int n) {
     if (!c->ev_stage) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
@@ -473,6 +505,8 @@ static int ensure_lu_streams(maus_ctx* c, int n) {
         int prio = (pe && atoi(pe) == 0) ? 0 : std::max(phi, std::min(plo, phi + idx));
         HIPCHK(c, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
         HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(e, s));                            // the hardware queue behind a stream is set up at its first
+        HIPCHK(c, hipEventSynchronize(e));                          // command: here, not inside the first batch that uses it
         c->lu_st.push_back(s); c->lu_done.push_back(e);
     }
     return 0;
@@ -504,6 +538,28 @@ static void mw_configure(const maus_ctx* c, LuWs& w) {
 }
 
 
+// generator-state and index buffers of sub-batch `sbi` (also called from maus_lu_reserve, so that the first batch that runs
+// as two sub-batches does not allocate inside somebody's timed step)
+static int mt_buf_reserve(maus_ctx* c, int sbi, int ngen, size_t nints) {
+    if ((int)c->mt_bufs.size() <= sbi) c->mt_bufs.resize(sbi + 1);
+    maus_ctx::MtBuf& mb = c->mt_bufs[sbi];
+    if (ngen > mb.cap) {
+        void** ps[] = {(void**)&mb.states, (void**)&mb.base};
+        for (auto p : ps) if (*p) { (void)hipFree(*p); *p = nullptr; }
+        const int cap = std::max(ngen, 4096);
+        HIPCHK(c, hipMalloc((void**)&mb.states, sizeof(uint32_t) * 624 * (size_t)cap));
+        HIPCHK(c, hipMalloc((void**)&mb.base, sizeof(uint32_t) * 624));
+        mb.cap = cap;
+    }
+    if (nints > mb.int_cap) {
+        if (mb.ints) { (void)hipFree(mb.ints); mb.ints = nullptr; }
+        const size_t cap = std::max<size_t>(nints * 2, 65536);
+        HIPCHK(c, hipMalloc((void**)&mb.ints, sizeof(int) * cap));
+        mb.int_cap = cap;
+    }
+    return 0;
+}
+
 // MAUS_PERT_MT19937: generator start states for candidates [first, first+g) of the run by binary lifting (over the
 // draw index m, then over the sub-stream index b), then the H build that regenerates the draws (mtdev.hip).  The plan
 // itself (pure host arithmetic on stream offsets) lives in mtplan.cpp so that it can be built and run under the CPU
@@ -518,14 +574,7 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
     const char* perr = nullptr;
     if (maus_mt_plan(d, n, first, g, s_override, &pl, &perr)) FAIL(c, perr ? perr : "maus_mt_plan failed");
     const int ngen = pl.ngen;
-    if (ngen > mb.cap) {
-        void** ps[] = {(void**)&mb.states, (void**)&mb.base};
-        for (auto p : ps) if (*p) { (void)hipFree(*p); *p = nullptr; }
-        const int cap = std::max(ngen, 4096);
-        HIPCHK(c, hipMalloc((void**)&mb.states, sizeof(uint32_t) * 624 * (size_t)cap));
-        HIPCHK(c, hipMalloc((void**)&mb.base, sizeof(uint32_t) * 624));
-        mb.cap = cap;
-    }
+    if (mt_buf_reserve(c, sbi, ngen, pl.hs.size())) return -1;
     struct DevLevel { size_t off; int count; MausJumpPolys P; int src_off; bool multi; };
     std::vector<DevLevel> levels;
     auto poly_taps = [&](uint64_t J, const int** taps_out, int* ntap16_out) -> int {     // tap list of x^J mod phi, cached on the device
@@ -554,12 +603,6 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
         levels.push_back(D);
     }
     const std::vector<int>& hs = pl.hs;
-    if (hs.size() > mb.int_cap) {
-        if (mb.ints) { (void)hipFree(mb.ints); mb.ints = nullptr; }
-        const size_t cap = hs.size() * 2;
-        HIPCHK(c, hipMalloc((void**)&mb.ints, sizeof(int) * cap));
-        mb.int_cap = cap;
-    }
     HIPCHK(c, hipMemcpyAsync(mb.base, d->key, sizeof(uint32_t) * 624, hipMemcpyHostToDevice, w.st));
     HIPCHK(c, hipMemcpyAsync(mb.ints, hs.data(), sizeof(int) * hs.size(), hipMemcpyHostToDevice, w.st));
     HIPCHK(c, hipStreamSynchronize(w.st));                       // staging (hs, d->key) is reusable from here on
@@ -587,7 +630,7 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
     // balanced chunks (271 candidates in a 256-matrix workspace run as 136 + 135, not 256 + 15)
     const int nchunks = (count + c->Hg - 1) / c->Hg;
     const int Gmax = (count + nchunks - 1) / nchunks;
-    const int nst = lu_stream_count();
+    const int nst = lu_stream_count(Gmax, c->Hnpad);
     if (ensure_lu_streams(c, nst)) return -1;
     std::vector<int> h_info(Gmax), h_flags(Gmax);
     for (int off = 0; off < count; off += Gmax) {
@@ -602,13 +645,13 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             HIPCHK(c, hipMemcpyAsync(c->Upert, (const double*)pert_data + 2 * (size_t)n * n * off, ub, hipMemcpyHostToDevice, c->st));
             dU = c->Upert;
         }
-        // One stream by default.  MAUS_LU_STREAMS=<n> splits a batch into min(n, G / MAUS_LU_MIN_SUB) sub-batches on their own
-        // streams so that the bandwidth- and latency-bound phases of one (panel, triangular solves, H build) run beside the
-        // MFMA-bound trailing updates of the others.  That paid 0-2 % while those phases ran at 2.4-4 TB/s (round 2, where a
-        // run-time tuner picked the count per batch-size class); with the tile-major workspace they run at ~5 TB/s, the
-        // zgemm beside them loses more than they gain, and whole driver-shaped runs give 352 / 338 candidate-steps/s with
-        // 1 / 2 streams (profiles/r03_streams_fixed.txt) -- the tuner, which picked three from one noisy sample per count, is gone.
-        // Results do not depend on the split (tests/test_gpu_bench_path.py: bit-equal).
+        // One stream at n = 4096 (lu_stream_count).  MAUS_LU_STREAMS=<n> splits a batch into min(n, G / MAUS_LU_MIN_SUB)
+        // sub-batches on their own streams so that the bandwidth- and latency-bound phases of one (panel, triangular solves,
+        // H build) run beside the MFMA-bound trailing updates of the others.  That paid 0-2 % while those phases ran at
+        // 2.4-4 TB/s (round 2, where a run-time tuner picked the count per batch-size class); with the tile-major workspace
+        // they run at ~5 TB/s, the zgemm beside them loses more than they gain, and whole driver-shaped runs give 352 / 338
+        // candidate-steps/s with 1 / 2 streams (profiles/r03_streams_fixed.txt) -- the tuner, which picked three from one
+        // noisy sample per count, is gone.  Results do not depend on the split (tests/test_gpu_bench_path.py: bit-equal).
         static const int min_sub = [] { const char* e = getenv("MAUS_LU_MIN_SUB"); return e ? std::max(1, atoi(e)) : 64; }();
         const int S = std::max(1, std::min(nst, G / min_sub));
         // One more pass without the multi-workgroup panel if a rendezvous of it timed out (info = INT_MIN): its premise --
@@ -704,6 +747,11 @@ int maus_lu_solve_host(maus_ctx* c, int count, int n, const double* a, const dou
 int maus_lu_reserve(maus_ctx* c, int n, int count, int* capacity_out) {
     if (n <= 0 || count < 0) FAIL(c, "maus_lu_reserve: bad sizes");
     if (count > 0 && ensure_lu_ws(c, n, count)) return -1;
+    if (count > 0 && c->H) {                                       // what a batch of the announced size will use (lu_stream_count)
+        const int nst = lu_stream_count(std::min(count, c->Hg), c->Hnpad);
+        if (ensure_lu_streams(c, nst)) return -1;
+        for (int sb = 0; sb < nst; ++sb) if (mt_buf_reserve(c, sb, 4096, 65536)) return -1;
+    }
     if (capacity_out) *capacity_out = (c->H && c->Hnpad == round_up(n, 32)) ? c->Hg : 0;
     return 0;
 }
@@ -815,12 +863,6 @@ int maus_herm_match(maus_ctx* c, const int* slots, int count, int32_t* idx_out, 
 // Gram block of candidate vectors (SURVEY f-2): G[i][j] = vdot(x_i, x_j) = sum_k conj(x_i[k]) x_j[k] over the rows
 // `slots` of population array `which`.  The rows are gathered into scratch once; the product is one zgemm in
 // dot-product layout with a conjugated left operand -- the same kernel as the Hermitian similarity row.
-__global__ void gather_rows_kernel(const c128* __restrict__ X, long ldx, const int* __restrict__ slots, int len,
-                                   c128* __restrict__ out) {
-    const c128* src = X + (long)slots[blockIdx.x] * ldx;
-    c128* dst = out + (long)blockIdx.x * len;
-    for (int k = threadIdx.x; k < len; k += blockDim.x) dst[k] = src[k];
-}
 
 int maus_gram(maus_ctx* c, int which, const int* slots, int count, int len, double* out_c128) {
     c128* X = (which == MAUS_POP_X) ? c->X : (which == MAUS_POP_U) ? c->U : (which == MAUS_POP_W) ? c->W : nullptr;

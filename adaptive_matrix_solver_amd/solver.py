@@ -617,6 +617,15 @@ class MAUS_Solver:
                 sp_["overall_psi_aggression_factor"] = max(sp_["overall_psi_aggression_factor"], 2.0)
             sp_["current_convergence_threshold"] = max(1e-5, sp_["convergence_tolerance"])
 
+    def _prefetch_converged(self):
+        """Host mirrors of the CONVERGED candidates' vectors with one transfer per array (AMS:432 / 510 read every one of them
+        through get_current_solution_params; one device-to-host copy per candidate was 40 us each -- 8 ms in the loop body in
+        which a few hundred candidates converge together)."""
+        C = SolutionCandidate.State
+        stale = [c for c in self.candidates if c.state == C.CONVERGED and not c._host_valid and c._engine is self.engine]
+        if len(stale) > 1:
+            self.engine._bulk_pull(stale)
+
     # ---- AMS:424-475 ------------------------------------------------------------------------------
     def _converged_gram(self):
         """(position map, |Gram| blocks) over the CONVERGED candidates in list order, or (None, None) when the set is
@@ -639,6 +648,7 @@ class MAUS_Solver:
 
     def _update_global_diagnostics(self, iteration):
         C = SolutionCandidate.State
+        self._prefetch_converged()
         gpos, gram = self._converged_gram()
         acc_pos, acc_key = [], []                          # Gram positions / lambda (sigma) of the accepted solutions
         total_active_candidates = len(self.candidates)
@@ -770,6 +780,7 @@ class MAUS_Solver:
         keys = [(-c.w_k, r) for c, r in zip(self.candidates, res_key)]
         sorted_candidates = [self.candidates[k] for k in sorted(range(len(keys)), key=keys.__getitem__)]
         tol = self.strat_params["convergence_tolerance"]
+        self._prefetch_converged()
         gpos, gram = self._converged_gram()
         sur_pos, sur_key = [], []                          # Gram positions / lambda (sigma) of the converged survivors
         for c in sorted_candidates:

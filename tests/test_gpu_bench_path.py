@@ -111,11 +111,12 @@ def test_eig4096_pop256_one_and_three_streams_against_host_and_lapack(ctx):
 
 
 def test_results_do_not_depend_on_the_sub_batch_stream_split():
-    """One stream is the default; MAUS_LU_STREAMS=n splits a batch into sub-batches on their own streams.  Whatever the
-    split, every call returns the same bits."""
+    """MAUS_LU_STREAMS=n splits a batch into sub-batches on their own streams; unset, a batch of more matrices than CUs at
+    n <= 1024 runs as two halves (300 here) and everything else on one stream.  Whatever the split, every call returns the
+    same bits."""
     from adaptive_matrix_solver_amd import Context
     from adaptive_matrix_solver_amd._cabi import PERT_MT19937
-    n, P = 160, 230
+    n, P = 160, 300
     A = scenarios.ginibre(n, 77, None)
     rng = np.random.default_rng(5)
     V = (rng.standard_normal((P, n)) + 1j * rng.standard_normal((P, n))) / np.sqrt(n)
@@ -131,7 +132,7 @@ def test_results_do_not_depend_on_the_sub_batch_stream_split():
         outs = {}
         for streams in (None, 1, 2, 3):
             with _env(MAUS_LU_STREAMS=streams):
-                for G in (230, 150, 100, 40):
+                for G in (300, 230, 150, 100, 40):
                     sl = list(range(G))
                     desc = (st, 4 * n * n, 0, np.arange(G, dtype=np.int32))
                     for rep in range(2):
@@ -141,8 +142,8 @@ def test_results_do_not_depend_on_the_sub_batch_stream_split():
                         if G in outs:
                             assert np.array_equal(W, outs[G]), (streams, G, rep)
                         outs[G] = W
-        HW = outs[230] @ A.T - (lam - psi)[:, None] * outs[230]
-        assert np.linalg.norm(HW - V, axis=1).max() <= 1e-10 * np.linalg.norm(A, 1) * np.linalg.norm(outs[230], axis=1).max()
+        HW = outs[300] @ A.T - (lam - psi)[:, None] * outs[300]
+        assert np.linalg.norm(HW - V, axis=1).max() <= 1e-10 * np.linalg.norm(A, 1) * np.linalg.norm(outs[300], axis=1).max()
     finally:
         c.close()
 

@@ -1,7 +1,7 @@
 """cProfile of loop bodies of a BASELINE configuration on the device (tools, not product): where the HOST time of a loop
 body goes once the kernels are fast.
 
-    python tools/host_profile.py c2|c3|c5 [loop bodies]
+    python tools/host_profile.py c2|c3|c4|c5 [loop bodies]        (c4: the profile starts at the FIRST loop body)
 """
 import cProfile, pstats, os, sys, random, io, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,8 +16,10 @@ elif cfg == "c2":
     A, PT, P = scenarios.ginibre(1024, 1024), ProblemType.EIGENVALUE, 256
 elif cfg == "c3":
     (A, bvec), PT, P = scenarios.wide_diag_system(4096, 4096, decades=7.0, offdiag=0.1), ProblemType.SOLVE_LINEAR_SYSTEM, 512
+elif cfg == "c4":
+    A, PT, P = scenarios.hermitian(int(os.environ.get("C4_N", "8192")), 8192), ProblemType.EIGENVALUE, 128
 else:
-    raise SystemExit("c2, c3 or c5")
+    raise SystemExit("c2, c3, c4 or c5")
 np.random.seed(1234); random.seed(1234); SolutionCandidate._candidate_id_counter = 0
 s = MAUS_Solver(A, PT, b_vector=bvec if cfg == "c3" else None, initial_num_candidates=P, quiet=True)
 S_ = SolutionCandidate.State
@@ -31,12 +33,13 @@ def body(it):
     return s.loop_body(it)
 
 
-body(1)
+if cfg != "c4":
+    body(1)
 s.engine.ctx.sync()
 pr = cProfile.Profile(); t0 = time.perf_counter(); pr.enable()
 act = 0
 for it in range(bodies):
-    act += body(2 + it)
+    act += body((1 if cfg == "c4" else 2) + it)
 s.engine.ctx.sync()
 pr.disable(); el = time.perf_counter() - t0
 print(f"{cfg}: {act} candidate steps in {bodies} loop bodies, {el * 1e3:.1f} ms, {el / act * 1e6:.1f} us per candidate step")

@@ -1,0 +1,18 @@
+"""First-call costs of maus_pop_get (tools, not product)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import numpy as np, scenarios
+from adaptive_matrix_solver_amd import Context
+n = 1024
+ctx = Context(0); ctx.set_matrix(scenarios.ginibre(n, 1)); ctx.pop_reserve(600)
+def t(label, f):
+    t0 = time.perf_counter(); f(); print(f"{label}: {(time.perf_counter() - t0) * 1e3:.2f} ms")
+t("gram 3 (small scratch first)", lambda: ctx.gram(0, [1, 5, 9], n))
+for rep in range(2):
+    t("1 row", lambda: ctx.pop_get(0, [5], n))
+    t("3 scattered rows", lambda: ctx.pop_get(0, [5, 9, 300], n))
+    t("11 scattered rows", lambda: ctx.pop_get(0, list(range(3, 300, 28)), n))
+    t("200 scattered rows", lambda: ctx.pop_get(0, list(range(1, 600, 3)), n))
+    t("64 contiguous rows", lambda: ctx.pop_get(0, list(range(64)), n))
+    t("gram 11", lambda: ctx.gram(0, list(range(3, 300, 28)), n))
