@@ -1,7 +1,6 @@
 // libmaus_hip C ABI (include/maus_hip.h): context, device memory, stream, and the batched
 // phases of the MAUS candidate step.  Host orchestration stays in Python (ctypes).
 #include <algorithm>
-#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,6 +42,106 @@ int ensure_scratch(maus_ctx* c, size_t bytes) {
     return 0;
 }
 
+// ---- pinned staging --------------------------------------------------------------------------------------------------------
+// A pageable buffer handed to hipMemcpy is pinned by the runtime and stays registered with the kernel driver.  When the caller
+// later frees it (NumPy temporaries, the vectors of retired candidates, a matrix copy of the start-up diagnostics), the driver
+// evicts the process's queues and re-validates every registered range before it restores them: 4-80 ms of idle GPU inside
+// somebody's loop body, and launches that appear 30x slower than they are (tools/userptr_probe.py; the slow second loop body
+// of BASELINE configs[2], the 20-40 ms first read-back of configs[3]).  A copy into fresh pageable memory is also staged page by
+// page by the runtime (16 MB: 20 ms against 0.6 ms + a memcpy).  So the library owns one pinned buffer per context and every
+// transfer of more than STAGE_DIRECT_MAX bytes goes through it; smaller ones are staged by the runtime itself.
+static const size_t STAGE_DIRECT_MAX = 16u << 10;
+// Small uploads are copied into a pinned ring and leave from there asynchronously; every entry point synchronises its streams
+// before it returns and uses far less than the ring between two such points, so a slot is never rewritten while in flight.
+static const size_t SMALL_RING = 2u << 20;
+
+int maus_pin_ready(maus_ctx* c) {
+    if (c->pin) return 0;
+    if (c->pin_failed) return -1;
+    const char* e = getenv("MAUS_PIN_BYTES");
+    const size_t want = e ? std::max<size_t>(1u << 20, (size_t)atoll(e)) : ((size_t)32 << 20);
+    if (hipHostMalloc(&c->pin, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->pin = nullptr; c->pin_failed = true; return -1; }
+    c->pin_bytes = want;
+    for (auto& ev : c->pin_ev) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; }
+    if (!c->pin_ev[0] || !c->pin_ev[1] || hipHostMalloc((void**)&c->pin_small, SMALL_RING, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_small = nullptr; c->pin_bytes = 0; c->pin_failed = true; return -1;
+    }
+    return 0;
+}
+
+int maus_stage_h2d(maus_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return 0;
+    if (maus_pin_ready(c)) {
+        HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        return 0;
+    }
+    const size_t half = c->pin_bytes / 2;
+    size_t off = 0;
+    for (int i = 0; off < bytes; ++i, off += half) {                // the memcpy of one half overlaps the DMA of the other
+        const int b = i & 1;
+        const size_t nb = std::min(half, bytes - off);
+        if (i >= 2) HIPCHK(c, hipEventSynchronize(c->pin_ev[b]));
+        memcpy((char*)c->pin + b * half, (const char*)src + off, nb);
+        HIPCHK(c, hipMemcpyAsync((char*)dst + off, (char*)c->pin + b * half, nb, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipEventRecord(c->pin_ev[b], st));
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    return 0;
+}
+
+int maus_stage_d2h(maus_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return 0;
+    if (maus_pin_ready(c)) {
+        HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        return 0;
+    }
+    const size_t half = c->pin_bytes / 2;
+    size_t off = 0, prev_off = 0, prev_nb = 0;
+    int i = 0;
+    for (; off < bytes; ++i, off += half) {
+        const int b = i & 1;
+        const size_t nb = std::min(half, bytes - off);
+        HIPCHK(c, hipMemcpyAsync((char*)c->pin + b * half, (const char*)src + off, nb, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipEventRecord(c->pin_ev[b], st));
+        if (i >= 1) {                                               // drain the other half while this one is in flight
+            HIPCHK(c, hipEventSynchronize(c->pin_ev[b ^ 1]));
+            memcpy((char*)dst + prev_off, (char*)c->pin + (b ^ 1) * half, prev_nb);
+        }
+        prev_off = off; prev_nb = nb;
+    }
+    const int lb = (i - 1) & 1;
+    HIPCHK(c, hipEventSynchronize(c->pin_ev[lb]));
+    memcpy((char*)dst + prev_off, (char*)c->pin + lb * half, prev_nb);
+    return 0;
+}
+
+// Small transfers stay asynchronous (the runtime stages them itself; the caller synchronises as before), larger ones are staged
+// and complete on return.
+int maus_h2d(maus_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return 0;
+    if (bytes > STAGE_DIRECT_MAX) return maus_stage_h2d(c, dst, src, bytes, st);
+    if (maus_pin_ready(c)) { HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); return 0; }
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (c->pin_small_off + need > SMALL_RING) c->pin_small_off = 0;
+    char* slot = c->pin_small + c->pin_small_off;
+    c->pin_small_off += need;
+    memcpy(slot, src, bytes);
+    HIPCHK(c, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, st));
+    return 0;
+}
+// complete on return (the destination is filled by a memcpy from the pinned buffer)
+int maus_d2h(maus_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return 0;
+    if (maus_pin_ready(c)) { HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st)); HIPCHK(c, hipStreamSynchronize(st)); return 0; }
+    if (bytes > c->pin_bytes / 2) return maus_stage_d2h(c, dst, src, bytes, st);
+    HIPCHK(c, hipMemcpyAsync(c->pin, src, bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    memcpy(dst, c->pin, bytes);
+    return 0;
+}
+
 int check_slots(maus_ctx* c, const int* slots, int count) {
     if (count < 0) FAIL(c, "negative count");
     for (int i = 0; i < count; ++i) if (slots[i] < 0 || slots[i] >= c->cap) FAIL(c, "slot out of range");
@@ -52,7 +151,7 @@ int check_slots(maus_ctx* c, const int* slots, int count) {
 int upload_slots(maus_ctx* c, const int* slots, int count) {
     if (check_slots(c, slots, count)) return -1;
     if (ensure_scalars(c, count)) return -1;
-    HIPCHK(c, hipMemcpyAsync(c->d_slots, slots, sizeof(int) * count, hipMemcpyHostToDevice, c->st));
+    if (maus_h2d(c, c->d_slots, slots, sizeof(int) * count, c->st)) return -1;
     return 0;
 }
 
@@ -121,6 +220,9 @@ int maus_ctx_destroy(maus_ctx* c) {
     void* ptrs[] = {c->A, c->b, c->V, c->X, c->U, c->W, c->Y, c->d_slots, c->d_i1, c->d_i2, c->d_c1, c->d_c2, c->d_r1, c->d_r2,
                     c->H, c->ipiv, c->perm, c->mw_sync, c->info, c->flags, c->Upert, c->scratch, c->hq, c->htau};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->pin) (void)hipHostFree(c->pin);
+    if (c->pin_small) (void)hipHostFree(c->pin_small);
+    for (auto ev : c->pin_ev) if (ev) (void)hipEventDestroy(ev);
     hist_free(c);
     for (auto& kv : c->mt_taps) if (kv.second.first) (void)hipFree(kv.second.first);
     for (auto& b : c->mt_bufs) { if (b.states) (void)hipFree(b.states); if (b.ints) (void)hipFree(b.ints); if (b.base) (void)hipFree(b.base); }
@@ -171,31 +273,27 @@ int maus_set_matrix(maus_ctx* c, const double* a, int rows, int cols) {
         c->rows = rows; c->cols = cols;
     }
     if (c->hq) { (void)hipFree(c->hq); c->hq = nullptr; } if (c->htau) { (void)hipFree(c->htau); c->htau = nullptr; } c->hqn = 0;   // reflectors of the previous matrix
-    HIPCHK(c, hipMemcpy(c->A, a, sizeof(c128) * (size_t)rows * cols, hipMemcpyHostToDevice));
-    return 0;
+    return maus_stage_h2d(c, c->A, a, sizeof(c128) * (size_t)rows * cols, c->st);
 }
 
 int maus_set_rhs(maus_ctx* c, const double* b, int n) {
     if (!b || n <= 0) FAIL(c, "maus_set_rhs: bad arguments");
     HIPCHK(c, hipStreamSynchronize(c->st));
     if (n != c->bn) { if (c->b) (void)hipFree(c->b); c->b = nullptr; HIPCHK(c, hipMalloc((void**)&c->b, sizeof(c128) * n)); c->bn = n; }
-    HIPCHK(c, hipMemcpy(c->b, b, sizeof(c128) * n, hipMemcpyHostToDevice));
-    return 0;
+    return maus_stage_h2d(c, c->b, b, sizeof(c128) * n, c->st);
 }
 
 int maus_set_eigvecs(maus_ctx* c, const double* v, int n) {
     if (!v || n <= 0 || n != c->rows || n != c->cols) FAIL(c, "maus_set_eigvecs: n must match the square problem matrix");
     HIPCHK(c, hipStreamSynchronize(c->st));
     if (n != c->vn) { if (c->V) (void)hipFree(c->V); c->V = nullptr; HIPCHK(c, hipMalloc((void**)&c->V, sizeof(c128) * (size_t)n * n)); c->vn = n; }
-    HIPCHK(c, hipMemcpy(c->V, v, sizeof(c128) * (size_t)n * n, hipMemcpyHostToDevice));
-    return 0;
+    return maus_stage_h2d(c, c->V, v, sizeof(c128) * (size_t)n * n, c->st);
 }
 
 int maus_get_eigvecs(maus_ctx* c, double* v_out, int n) {
     if (!c->V || c->vn != n || !v_out) FAIL(c, "maus_get_eigvecs: no eigenvector matrix of that order on the device");
     HIPCHK(c, hipStreamSynchronize(c->st));
-    HIPCHK(c, hipMemcpy(v_out, c->V, sizeof(c128) * (size_t)n * n, hipMemcpyDeviceToHost));
-    return 0;
+    return maus_stage_d2h(c, v_out, c->V, sizeof(c128) * (size_t)n * n, c->st);
 }
 
 int maus_pop_capacity(maus_ctx* c) { return c->cap; }
@@ -219,6 +317,7 @@ int maus_pop_reserve(maus_ctx* c, int capacity) {
     // runtime loads its strided-copy kernel at the first hipMemcpy2D (8 ms measured), and the gather scratch of maus_pop_get /
     // maus_gram would otherwise be (re)allocated there.
     if (ensure_scratch(c, sizeof(c128) * (size_t)std::min(newcap, 256) * ld)) return -1;
+    (void)maus_pin_ready(c);                                        // without it the direct copies remain
     { std::vector<c128> tmp(2 * 8);
       HIPCHK(c, hipMemcpy2DAsync(tmp.data(), sizeof(c128) * 8, c->X, sizeof(c128) * ld, sizeof(c128) * std::min<long>(8, ld), std::min(2, newcap), hipMemcpyDeviceToHost, c->st));
       HIPCHK(c, hipStreamSynchronize(c->st)); }
@@ -235,19 +334,41 @@ static bool contiguous(const int* slots, int count) {
     return true;
 }
 
+// Candidate vectors cross the bus through the context's pinned buffer (maus_pop_reserve), never straight from / into the
+// caller's arrays.  Two reasons, both measured (tools/popget_probe.py, tools/userptr_probe.py): a copy into fresh pageable
+// memory is staged page by page by the runtime (16 MB: 20 ms against 0.6 ms + a memcpy), and a caller buffer handed to
+// hipMemcpy is registered with the driver -- when NumPy later frees it, the next submission of this process waits for the
+// driver's invalidation work (4-40 ms of idle GPU inside somebody's loop body).
 int maus_pop_put(maus_ctx* c, int which, const int* slots, int count, const double* host, int len) {
     c128* P = pop_array(c, which);
     if (!P) FAIL(c, "maus_pop_put: population not reserved / bad array id");
     if (len <= 0 || len > c->ldp) FAIL(c, "maus_pop_put: bad vector length");
     if (check_slots(c, slots, count)) return -1;
     if (count == 0) return 0;
-    if (contiguous(slots, count)) {
-        HIPCHK(c, hipMemcpy2DAsync(P + (long)slots[0] * c->ldp, sizeof(c128) * c->ldp, host, sizeof(c128) * len, sizeof(c128) * len, count, hipMemcpyHostToDevice, c->st));
-    } else {
-        for (int i = 0; i < count; ++i)
-            HIPCHK(c, hipMemcpyAsync(P + (long)slots[i] * c->ldp, host + 2 * (size_t)i * len, sizeof(c128) * len, hipMemcpyHostToDevice, c->st));
+    const size_t rowb = sizeof(c128) * (size_t)len;
+    if (!c->pin || c->pin_bytes < rowb) {                          // no staging buffer: straight from the caller's memory
+        if (contiguous(slots, count)) {
+            HIPCHK(c, hipMemcpy2DAsync(P + (long)slots[0] * c->ldp, sizeof(c128) * c->ldp, host, rowb, rowb, count, hipMemcpyHostToDevice, c->st));
+        } else {
+            for (int i = 0; i < count; ++i)
+                HIPCHK(c, hipMemcpyAsync(P + (long)slots[i] * c->ldp, host + 2 * (size_t)i * len, rowb, hipMemcpyHostToDevice, c->st));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        return 0;
     }
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    const int per = (int)(c->pin_bytes / rowb);
+    for (int off = 0; off < count; off += per) {
+        const int k = std::min(per, count - off);
+        memcpy(c->pin, host + 2 * (size_t)off * len, rowb * k);
+        if (contiguous(slots + off, k)) {
+            if (k == 1) HIPCHK(c, hipMemcpyAsync(P + (long)slots[off] * c->ldp, c->pin, rowb, hipMemcpyHostToDevice, c->st));
+            else HIPCHK(c, hipMemcpy2DAsync(P + (long)slots[off] * c->ldp, sizeof(c128) * c->ldp, c->pin, rowb, rowb, k, hipMemcpyHostToDevice, c->st));
+        } else {
+            for (int i = 0; i < k; ++i)
+                HIPCHK(c, hipMemcpyAsync(P + (long)slots[off + i] * c->ldp, (const char*)c->pin + rowb * i, rowb, hipMemcpyHostToDevice, c->st));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->st));                     // the buffer is reused by the next chunk / call
+    }
     return 0;
 }
 
@@ -265,20 +386,38 @@ int maus_pop_get(maus_ctx* c, int which, const int* slots, int count, double* ho
     if (len <= 0 || len > c->ldp) FAIL(c, "maus_pop_get: bad vector length");
     if (check_slots(c, slots, count)) return -1;
     if (count == 0) return 0;
-    if (count == 1) {
-        HIPCHK(c, hipMemcpyAsync(host, P + (long)slots[0] * c->ldp, sizeof(c128) * len, hipMemcpyDeviceToHost, c->st));
-    } else if (contiguous(slots, count)) {
-        HIPCHK(c, hipMemcpy2DAsync(host, sizeof(c128) * len, P + (long)slots[0] * c->ldp, sizeof(c128) * c->ldp, sizeof(c128) * len, count, hipMemcpyDeviceToHost, c->st));
-    } else if (count < 4) {
-        for (int i = 0; i < count; ++i)
-            HIPCHK(c, hipMemcpyAsync(host + 2 * (size_t)i * len, P + (long)slots[i] * c->ldp, sizeof(c128) * len, hipMemcpyDeviceToHost, c->st));
-    } else {                                                        // scattered rows: gather on the device, one copy
-        if (upload_slots(c, slots, count)) return -1;
-        if (ensure_scratch(c, sizeof(c128) * (size_t)count * len)) return -1;
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(count), dim3(256), 0, c->st, P, c->ldp, c->d_slots, len, (c128*)c->scratch);
-        HIPCHK(c, hipMemcpyAsync(host, c->scratch, sizeof(c128) * (size_t)count * len, hipMemcpyDeviceToHost, c->st));
+    const size_t rowb = sizeof(c128) * (size_t)len;
+    if (!c->pin || c->pin_bytes < rowb + sizeof(int) * 4) {        // no staging buffer: straight into the caller's memory
+        if (contiguous(slots, count)) {
+            HIPCHK(c, hipMemcpy2DAsync(host, rowb, P + (long)slots[0] * c->ldp, sizeof(c128) * c->ldp, rowb, count, hipMemcpyDeviceToHost, c->st));
+        } else {
+            for (int i = 0; i < count; ++i)
+                HIPCHK(c, hipMemcpyAsync(host + 2 * (size_t)i * len, P + (long)slots[i] * c->ldp, rowb, hipMemcpyDeviceToHost, c->st));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        return 0;
     }
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    const int per = (int)(c->pin_bytes / rowb);
+    for (int off = 0; off < count; off += per) {
+        const int k = std::min(per, count - off);
+        if (k == 1) {
+            HIPCHK(c, hipMemcpyAsync(c->pin, P + (long)slots[off] * c->ldp, rowb, hipMemcpyDeviceToHost, c->st));
+        } else if (contiguous(slots + off, k)) {
+            HIPCHK(c, hipMemcpy2DAsync(c->pin, rowb, P + (long)slots[off] * c->ldp, sizeof(c128) * c->ldp, rowb, k, hipMemcpyDeviceToHost, c->st));
+        } else if (k < 4) {
+            for (int i = 0; i < k; ++i)
+                HIPCHK(c, hipMemcpyAsync((char*)c->pin + rowb * i, P + (long)slots[off + i] * c->ldp, rowb, hipMemcpyDeviceToHost, c->st));
+        } else {                                                    // scattered rows: gather on the device, one copy
+            if (ensure_scalars(c, k)) return -1;
+            if (ensure_scratch(c, rowb * k)) return -1;
+            memcpy(c->pin, slots + off, sizeof(int) * k);            // (consumed by the gather before the rows land on it)
+            HIPCHK(c, hipMemcpyAsync(c->d_slots, c->pin, sizeof(int) * k, hipMemcpyHostToDevice, c->st));
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(k), dim3(256), 0, c->st, P, c->ldp, c->d_slots, len, (c128*)c->scratch);
+            HIPCHK(c, hipMemcpyAsync(c->pin, c->scratch, rowb * k, hipMemcpyDeviceToHost, c->st));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        memcpy(host + 2 * (size_t)off * len, c->pin, rowb * k);
+    }
     return 0;
 }
 
@@ -358,7 +497,7 @@ int maus_hist_append(maus_ctx* c, int which, const int* slots, int count, int le
                 old->host = (c128*)malloc(ob);
                 if (!old->host) FAIL(c, "maus_hist_append: out of host memory");
                 HIPCHK(c, hipStreamSynchronize(c->st));
-                HIPCHK(c, hipMemcpy(old->host, old->dev, sizeof(c128) * (size_t)len * old->rows, hipMemcpyDeviceToHost));
+                if (maus_stage_d2h(c, old->host, old->dev, sizeof(c128) * (size_t)len * old->rows, c->st)) return -1;
                 (void)hipFree(old->dev); old->dev = nullptr; c->hist_dev_bytes -= ob;
             }
             HIPCHK(c, hipMalloc((void**)&h.dev, bytes));
@@ -384,10 +523,9 @@ int maus_hist_get(maus_ctx* c, const int64_t* indices, int count, int len, doubl
         const auto& h = c->hist[(size_t)(ix / chunk_rows)];
         const size_t off = (size_t)(ix % chunk_rows) * c->hist_len;
         double* out = host_c128 + 2 * (size_t)i * len;
-        if (h.dev) HIPCHK(c, hipMemcpyAsync(out, h.dev + off, sizeof(c128) * len, hipMemcpyDeviceToHost, c->st));
+        if (h.dev) { if (maus_stage_d2h(c, out, h.dev + off, sizeof(c128) * len, c->st)) return -1; }
         else memcpy(out, h.host + off, sizeof(c128) * len);
     }
-    HIPCHK(c, hipStreamSynchronize(c->st));
     return 0;
 }
 
@@ -406,8 +544,8 @@ int maus_matvec_rayleigh(maus_ctx* c, const int* slots, int count, double* num, 
     matvec_into_Y(c, c->X, count);
     { ProfScope ps(c, KC_VEC, 0, 32.0 * count * c->rows);
       maus_launch_rayleigh_dots(c->st, c->X, c->Y, c->ldp, c->d_slots, count, c->rows, c->d_c1, c->d_c2); }
-    HIPCHK(c, hipMemcpyAsync(num, c->d_c1, sizeof(c128) * count, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(den, c->d_c2, sizeof(c128) * count, hipMemcpyDeviceToHost, c->st));
+    if (maus_d2h(c, num, c->d_c1, sizeof(c128) * count, c->st)) return -1;
+    if (maus_d2h(c, den, c->d_c2, sizeof(c128) * count, c->st)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->st));
     return 0;
 }
@@ -603,8 +741,8 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
         levels.push_back(D);
     }
     const std::vector<int>& hs = pl.hs;
-    HIPCHK(c, hipMemcpyAsync(mb.base, d->key, sizeof(uint32_t) * 624, hipMemcpyHostToDevice, w.st));
-    HIPCHK(c, hipMemcpyAsync(mb.ints, hs.data(), sizeof(int) * hs.size(), hipMemcpyHostToDevice, w.st));
+    if (maus_h2d(c, mb.base, d->key, sizeof(uint32_t) * 624, w.st)) return -1;
+    if (maus_h2d(c, mb.ints, hs.data(), sizeof(int) * hs.size(), w.st)) return -1;
     HIPCHK(c, hipStreamSynchronize(w.st));                       // staging (hs, d->key) is reusable from here on
     maus_mt_copy_states(w.st, mb.states, mb.base, ngen);
     for (const DevLevel& L : levels) maus_mt_jump(w.st, mb.states, mb.ints + L.off, L.multi ? mb.ints + L.off + L.count : nullptr, L.count, L.P, L.src_off);
@@ -635,14 +773,14 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
     std::vector<int> h_info(Gmax), h_flags(Gmax);
     for (int off = 0; off < count; off += Gmax) {
         const int G = std::min(Gmax, count - off);
-        HIPCHK(c, hipMemcpyAsync(c->d_slots, slots + off, sizeof(int) * G, hipMemcpyHostToDevice, c->st));
-        HIPCHK(c, hipMemcpyAsync(c->d_c1, shift + 2 * (size_t)off, sizeof(c128) * G, hipMemcpyHostToDevice, c->st));
-        HIPCHK(c, hipMemcpyAsync(c->d_r1, psi + off, sizeof(double) * G, hipMemcpyHostToDevice, c->st));
+        if (maus_h2d(c, c->d_slots, slots + off, sizeof(int) * G, c->st)) return -1;
+        if (maus_h2d(c, c->d_c1, shift + 2 * (size_t)off, sizeof(c128) * G, c->st)) return -1;
+        if (maus_h2d(c, c->d_r1, psi + off, sizeof(double) * G, c->st)) return -1;
         const double* dU = nullptr;
         if (pert_mode == MAUS_PERT_UNIFORM) {
             size_t ub = sizeof(double) * 2 * (size_t)n * n * G;
             if (ub > c->Ubytes) { if (c->Upert) (void)hipFree(c->Upert); c->Upert = nullptr; HIPCHK(c, hipMalloc((void**)&c->Upert, ub)); c->Ubytes = ub; }
-            HIPCHK(c, hipMemcpyAsync(c->Upert, (const double*)pert_data + 2 * (size_t)n * n * off, ub, hipMemcpyHostToDevice, c->st));
+            if (maus_stage_h2d(c, c->Upert, (const double*)pert_data + 2 * (size_t)n * n * off, ub, c->st)) return -1;
             dU = c->Upert;
         }
         // One stream at n = 4096 (lu_stream_count).  MAUS_LU_STREAMS=<n> splits a batch into min(n, G / MAUS_LU_MIN_SUB)
@@ -689,8 +827,8 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             if (S > 1) { HIPCHK(c, hipEventRecord(c->lu_done[i], wss[i].st)); HIPCHK(c, hipStreamWaitEvent(c->st, c->lu_done[i], 0)); }
         }
         c->prof_st = nullptr;
-        HIPCHK(c, hipMemcpyAsync(h_info.data(), c->info, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
-        HIPCHK(c, hipMemcpyAsync(h_flags.data(), c->flags, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
+        if (maus_d2h(c, h_info.data(), c->info, sizeof(int) * G, c->st)) return -1;
+        if (maus_d2h(c, h_flags.data(), c->flags, sizeof(int) * G, c->st)) return -1;
         HIPCHK(c, hipStreamSynchronize(c->st));
         HIPCHK(c, hipGetLastError());
         if (any_internal_failure(G, h_info.data())) {
@@ -714,8 +852,8 @@ int maus_lu_solve_host(maus_ctx* c, int count, int n, const double* a, const dou
     std::vector<int> h_info(Gmax), h_flags(Gmax);
     for (int off = 0; off < count; off += Gmax) {
         const int G = std::min(Gmax, count - off);
-        HIPCHK(c, hipMemcpyAsync(dA, a + 2 * (size_t)n * n * off, ab * G, hipMemcpyHostToDevice, c->st));
-        HIPCHK(c, hipMemcpyAsync(dB, b + 2 * (size_t)n * off, bb * G, hipMemcpyHostToDevice, c->st));
+        if (maus_stage_h2d(c, dA, a + 2 * (size_t)n * n * off, ab * G, c->st)) return -1;
+        if (maus_stage_h2d(c, dB, b + 2 * (size_t)n * off, bb * G, c->st)) return -1;
         for (int pass = 0; pass < 2; ++pass) {
         LuWs w = make_ws(c, n, G);
         mw_configure(c, w);
@@ -724,9 +862,9 @@ int maus_lu_solve_host(maus_ctx* c, int count, int n, const double* a, const dou
         maus_load_h(w, dA, dB);
         maus_lu_factor(w, lu_nbo());
         maus_lu_backsolve(w, nullptr, 0, nullptr, dX);
-        HIPCHK(c, hipMemcpyAsync(x + 2 * (size_t)n * off, dX, bb * G, hipMemcpyDeviceToHost, c->st));
-        HIPCHK(c, hipMemcpyAsync(h_info.data(), c->info, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
-        HIPCHK(c, hipMemcpyAsync(h_flags.data(), c->flags, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
+        if (maus_stage_d2h(c, x + 2 * (size_t)n * off, dX, bb * G, c->st)) return -1;
+        if (maus_d2h(c, h_info.data(), c->info, sizeof(int) * G, c->st)) return -1;
+        if (maus_d2h(c, h_flags.data(), c->flags, sizeof(int) * G, c->st)) return -1;
         if (ipiv_out) {
             // ipiv rows are npad long on the device; return the first n of each
             HIPCHK(c, hipMemcpy2DAsync(ipiv_out + (size_t)off * n, sizeof(int) * n, c->ipiv, sizeof(int) * c->Hnpad, sizeof(int) * n, G, hipMemcpyDeviceToHost, c->st));
@@ -767,10 +905,10 @@ int maus_relax_normalise(maus_ctx* c, const int* slots, int count, const double*
     if (count == 0) return 0;
     if (upload_slots(c, slots, count)) return -1;
     const int n = c->rows;
-    HIPCHK(c, hipMemcpyAsync(c->d_c1, alpha, sizeof(c128) * count, hipMemcpyHostToDevice, c->st));
+    if (maus_h2d(c, c->d_c1, alpha, sizeof(c128) * count, c->st)) return -1;
     { ProfScope ps(c, KC_VEC, 0, 48.0 * count * n);
       maus_launch_relax(c->st, c->X, c->W, c->ldp, c->d_slots, count, n, c->d_c1, normalise, c->d_r1); }
-    HIPCHK(c, hipMemcpyAsync(norm_out, c->d_r1, sizeof(double) * count, hipMemcpyDeviceToHost, c->st));
+    if (maus_d2h(c, norm_out, c->d_r1, sizeof(double) * count, c->st)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->st));
     return 0;
 }
@@ -783,13 +921,13 @@ int maus_residual(maus_ctx* c, int kind, const int* slots, int count, const doub
         if (c->rows != c->cols) FAIL(c, "maus_residual: square matrix required");
         if (kind == MAUS_LINEAR && (!c->b || c->bn != c->rows)) FAIL(c, "maus_residual: rhs b not set");
         if (kind == MAUS_EIG && !lam) FAIL(c, "maus_residual: lambda missing");
-        if (lam) HIPCHK(c, hipMemcpyAsync(c->d_c1, lam, sizeof(c128) * count, hipMemcpyHostToDevice, c->st));
+        if (lam) { if (maus_h2d(c, c->d_c1, lam, sizeof(c128) * count, c->st)) return -1; }
         matvec_into_Y(c, c->X, count);
         { ProfScope ps(c, KC_VEC, 0, 32.0 * count * c->rows);
           maus_launch_residual(c->st, kind, c->X, c->Y, c->ldp, c->d_slots, count, c->rows, lam ? c->d_c1 : nullptr, c->b, c->d_r1, c->d_i1); }
     } else if (kind == MAUS_SVD) {
         if (!lam) FAIL(c, "maus_residual: sigma missing");
-        HIPCHK(c, hipMemcpyAsync(c->d_c1, lam, sizeof(c128) * count, hipMemcpyHostToDevice, c->st));
+        if (maus_h2d(c, c->d_c1, lam, sizeof(c128) * count, c->st)) return -1;
         // ||A v - s u||  : Y = X * A^T  (count x rows)
         matvec_into_Y(c, c->X, count);
         maus_launch_svd_resid(c->st, c->Y, c->U, c->ldp, c->d_slots, count, c->rows, c->d_c1, c->d_r1, 0, c->d_i1);
@@ -799,8 +937,8 @@ int maus_residual(maus_ctx* c, int kind, const int* slots, int count, const doub
                                 1.0, 0, 1, 0, false, true, c->d_slots, c->d_slots); }
         maus_launch_svd_resid(c->st, c->W, c->X, c->ldp, c->d_slots, count, c->cols, c->d_c1, c->d_r1, 1, c->d_i1);
     } else FAIL(c, "maus_residual: unknown kind");
-    HIPCHK(c, hipMemcpyAsync(resid, c->d_r1, sizeof(double) * count, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(finite, c->d_i1, sizeof(int) * count, hipMemcpyDeviceToHost, c->st));
+    if (maus_d2h(c, resid, c->d_r1, sizeof(double) * count, c->st)) return -1;
+    if (maus_d2h(c, finite, c->d_i1, sizeof(int) * count, c->st)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->st));
     return 0;
 }
@@ -825,7 +963,7 @@ int maus_svd_power_propose(maus_ctx* c, const int* slots, int count, double* nor
       maus_zgemm_launch_idx(c->st, count, c->cols, c->rows, c->Y, c->ldp, 0, c->A, c->cols, 0, c->W, c->ldp, 0,
                             1.0, 0, 1, 0, false, true, c->d_slots, c->d_slots); }
     maus_launch_norm_scale(c->st, c->W, c->W, c->ldp, c->d_slots, count, c->cols, c->d_r1, 4, 3);
-    HIPCHK(c, hipMemcpyAsync(norms_out, c->d_r1, sizeof(double) * 4 * count, hipMemcpyDeviceToHost, c->st));
+    if (maus_d2h(c, norms_out, c->d_r1, sizeof(double) * 4 * count, c->st)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->st));
     return 0;
 }
@@ -854,8 +992,8 @@ int maus_herm_match(maus_ctx* c, const int* slots, int count, int32_t* idx_out, 
     { ProfScope ps(c, KC_GEMM, 8.0 * count * n * n, 16.0 * (double)n * n);
       maus_zgemm_launch_idx(c->st, count, n, n, c->X, c->ldp, 0, c->V, n, 0, c->Y, c->ldp, 0, 1.0, 0, 1, 0, true, false, c->d_slots, c->d_slots); }
     maus_launch_herm_pick(c->st, c->Y, c->ldp, c->X, c->ldp, c->d_slots, count, c->V, n, c->d_i1, c->d_r1);
-    HIPCHK(c, hipMemcpyAsync(idx_out, c->d_i1, sizeof(int) * count, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(norm_out, c->d_r1, sizeof(double) * count, hipMemcpyDeviceToHost, c->st));
+    if (maus_d2h(c, idx_out, c->d_i1, sizeof(int) * count, c->st)) return -1;
+    if (maus_d2h(c, norm_out, c->d_r1, sizeof(double) * count, c->st)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->st));
     return 0;
 }
@@ -876,8 +1014,7 @@ int maus_gram(maus_ctx* c, int which, const int* slots, int count, int len, doub
     hipLaunchKernelGGL(gather_rows_kernel, dim3(count), dim3(256), 0, c->st, X, c->ldp, c->d_slots, len, R);
     { ProfScope ps(c, KC_GEMM, 8.0 * count * count * len, 16.0 * (2.0 * rows + g));
       maus_zgemm_launch_idx(c->st, count, count, len, R, len, 0, R, len, 0, G, count, 0, 1.0, 0, 1, 1, true, false, nullptr, nullptr); }
-    HIPCHK(c, hipMemcpyAsync(out_c128, G, sizeof(c128) * g, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (maus_stage_d2h(c, out_c128, G, sizeof(c128) * g, c->st)) return -1;
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -903,23 +1040,23 @@ int maus_gmres_pert(maus_ctx* c, const int* slots, int count, const double* shif
     std::vector<int> h_flags(std::min(count, c->Hg));
     for (int off = 0; off < count; off += c->Hg) {                     // chunks of at most the workspace capacity
         const int G = std::min(c->Hg, count - off);
-        HIPCHK(c, hipMemcpyAsync(c->d_slots, slots + off, sizeof(int) * G, hipMemcpyHostToDevice, c->st));
-        HIPCHK(c, hipMemcpyAsync(c->d_c1, shift + 2 * (size_t)off, sizeof(c128) * G, hipMemcpyHostToDevice, c->st));
-        HIPCHK(c, hipMemcpyAsync(c->d_r1, psi + off, sizeof(double) * G, hipMemcpyHostToDevice, c->st));
+        if (maus_h2d(c, c->d_slots, slots + off, sizeof(int) * G, c->st)) return -1;
+        if (maus_h2d(c, c->d_c1, shift + 2 * (size_t)off, sizeof(c128) * G, c->st)) return -1;
+        if (maus_h2d(c, c->d_r1, psi + off, sizeof(double) * G, c->st)) return -1;
         HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(int) * G, c->st));
         LuWs w = make_ws(c, n, G);
         const double* dU = nullptr;
         if (pert_mode == MAUS_PERT_UNIFORM) {
             size_t ub = sizeof(double) * 2 * (size_t)n * n * G;
             if (ub > c->Ubytes) { if (c->Upert) (void)hipFree(c->Upert); c->Upert = nullptr; HIPCHK(c, hipMalloc((void**)&c->Upert, ub)); c->Ubytes = ub; }
-            HIPCHK(c, hipMemcpyAsync(c->Upert, (const double*)pert_data + 2 * (size_t)n * n * off, ub, hipMemcpyHostToDevice, c->st));
+            if (maus_stage_h2d(c, c->Upert, (const double*)pert_data + 2 * (size_t)n * n * off, ub, c->st)) return -1;
             dU = c->Upert;
         }
         if (pert_mode == MAUS_PERT_MT19937) {
             if (mt_prepare_and_build(c, w, (const maus_mt_desc*)pert_data, off, G, rhs_mode, 0, 0, 0)) return -1;
         } else
             maus_build_h(w, c->A, c->d_c1, c->d_r1, rhs_mode, c->X, c->ldp, c->d_slots, c->b, pert_mode, dU, 0);     // row-major: one dense GEMV operand per candidate
-        HIPCHK(c, hipMemcpyAsync(h_flags.data(), c->flags, sizeof(int) * G, hipMemcpyDeviceToHost, c->st));
+        if (maus_d2h(c, h_flags.data(), c->flags, sizeof(int) * G, c->st)) return -1;
         if (maus_gmres_run(c, slots + off, G, shift + 2 * (size_t)off, psi + off, rhs_mode, want_jacobi + off, rtol, restart, maxiter,
                            info_out + off, inner_out + off, status + off, w.H, w.ldh, w.strideH, jacobi_out ? jacobi_out + off : nullptr))
             return -1;
@@ -937,13 +1074,11 @@ int maus_zgemm_host(maus_ctx* c, int M, int N, int K, const double* A, const dou
     size_t ea = (size_t)M * K, eb = (size_t)K * N, ec = (size_t)M * N;
     if (ensure_scratch(c, sizeof(c128) * (ea + eb + ec))) return -1;
     c128* dA = (c128*)c->scratch; c128* dB = dA + ea; c128* dC = dB + eb;
-    HIPCHK(c, hipMemcpyAsync(dA, A, sizeof(c128) * ea, hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipMemcpyAsync(dB, B, sizeof(c128) * eb, hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipMemcpyAsync(dC, C, sizeof(c128) * ec, hipMemcpyHostToDevice, c->st));
+    if (maus_stage_h2d(c, dA, A, sizeof(c128) * ea, c->st) || maus_stage_h2d(c, dB, B, sizeof(c128) * eb, c->st)
+        || maus_stage_h2d(c, dC, C, sizeof(c128) * ec, c->st)) return -1;
     { ProfScope ps(c, KC_GEMM, 8.0 * M * N * K, 16.0 * (ea + eb + 2.0 * ec));
       maus_zgemm_launch_idx(c->st, M, N, K, dA, K, 0, dB, b_layout ? K : N, 0, dC, N, 0, alpha, beta, 1, b_layout, conj_a != 0, conj_b != 0, nullptr, nullptr); }
-    HIPCHK(c, hipMemcpyAsync(C, dC, sizeof(c128) * ec, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (maus_stage_d2h(c, C, dC, sizeof(c128) * ec, c->st)) return -1;
     HIPCHK(c, hipGetLastError());
     return 0;
 }

@@ -156,10 +156,12 @@ int maus_comm_allgather_records(maus_ctx* c, const void* send, size_t bytes_per_
     Timer tm(c, (double)bytes_per_rank * W);
     if (ensure_comm_buf(c, chunk * (W + 1))) return -1;
     char* d_send = (char*)c->comm_buf; char* d_recv = d_send + chunk;
-    HIPCHK(c, hipMemcpyAsync(d_send, send, bytes_per_rank, hipMemcpyHostToDevice, c->st));
+    // host buffers cross through the context's pinned buffer (capi.hip, "pinned staging"): the caller's arrays are short-lived
+    if (maus_stage_h2d(c, d_send, send, bytes_per_rank, c->st)) return -1;
     NCCLCHK(c, rccl()->AllGather(d_send, d_recv, chunk, ncclChar, (ncclComm_t)c->comm, c->st));
-    HIPCHK(c, hipMemcpy2DAsync(recv, bytes_per_rank, d_recv, chunk, bytes_per_rank, W, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (chunk == bytes_per_rank) return maus_stage_d2h(c, recv, d_recv, chunk * W, c->st);
+    for (size_t r = 0; r < W; ++r)
+        if (maus_stage_d2h(c, (char*)recv + r * bytes_per_rank, d_recv + r * chunk, bytes_per_rank, c->st)) return -1;
     return 0;
 }
 
@@ -193,7 +195,7 @@ int maus_comm_allgather_rows(maus_ctx* c, int which, const int* slots, const int
     int* d_ints = (int*)c->comm_buf;
     c128* d_send = (c128*)((char*)c->comm_buf + ints_bytes);
     c128* d_recv = d_send + (size_t)cmax * len;
-    HIPCHK(c, hipMemcpyAsync(d_ints, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, c->st));
+    if (maus_h2d(c, d_ints, h.data(), sizeof(int) * h.size(), c->st)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->st));                         // h is about to go out of scope
     if (counts[me] > 0)
         hipLaunchKernelGGL(pack_rows_kernel, dim3(counts[me]), dim3(256), 0, c->st, P, c->ldp, d_ints + my_off, len, d_send);
@@ -216,10 +218,10 @@ int maus_comm_bcast(maus_ctx* c, void* buf, size_t bytes, int root) {
     if (ensure_comm_buf(c, std::min(bytes, chunk))) return -1;
     for (size_t off = 0; off < bytes; off += chunk) {
         const size_t nb = std::min(chunk, bytes - off);
-        if (c->comm_rank == root) HIPCHK(c, hipMemcpyAsync(c->comm_buf, (char*)buf + off, nb, hipMemcpyHostToDevice, c->st));
+        if (c->comm_rank == root && maus_stage_h2d(c, c->comm_buf, (char*)buf + off, nb, c->st)) return -1;
         NCCLCHK(c, rccl()->Broadcast(c->comm_buf, c->comm_buf, nb, ncclChar, root, (ncclComm_t)c->comm, c->st));
-        if (c->comm_rank != root) HIPCHK(c, hipMemcpyAsync((char*)buf + off, c->comm_buf, nb, hipMemcpyDeviceToHost, c->st));
-        HIPCHK(c, hipStreamSynchronize(c->st));
+        if (c->comm_rank != root) { if (maus_stage_d2h(c, (char*)buf + off, c->comm_buf, nb, c->st)) return -1; }
+        else HIPCHK(c, hipStreamSynchronize(c->st));
     }
     return 0;
 }

@@ -91,6 +91,9 @@ struct maus_ctx {
     long comm_calls = 0; double comm_bytes = 0, comm_ms = 0;
     // generic scratch (host-GEMM / host-LU test entry points, GMRES)
     void* scratch = nullptr; size_t scratch_bytes = 0;
+    void* pin = nullptr; size_t pin_bytes = 0;           // pinned host staging buffer (maus_stage_h2d / _d2h, maus_pop_put / _get)
+    hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_failed = false;
+    char* pin_small = nullptr; size_t pin_small_off = 0;   // pinned ring for small asynchronous uploads (maus_h2d)
     // measurement
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool prof_on = false;
@@ -118,6 +121,13 @@ int ensure_scalars(maus_ctx* c, int count);
 int ensure_scratch(maus_ctx* c, size_t bytes);
 int check_slots(maus_ctx* c, const int* slots, int count);
 int upload_slots(maus_ctx* c, const int* slots, int count);
+// Host <-> device copies of anything larger than a few KB go through the context's pinned buffer, never straight from / into the
+// caller's memory (capi.hip).  Both are synchronous with respect to `st`.
+int maus_pin_ready(maus_ctx* c);
+int maus_stage_h2d(maus_ctx* c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t st);
+int maus_stage_d2h(maus_ctx* c, void* dst_host, const void* src_dev, size_t bytes, hipStream_t st);
+int maus_h2d(maus_ctx* c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t st);   // <= 16 KB: asynchronous (the source is copied out before it returns)
+int maus_d2h(maus_ctx* c, void* dst_host, const void* src_dev, size_t bytes, hipStream_t st);
 void prof_tick(void* ud, int klass, int phase, double flops, double bytes);
 
 struct ProfScope {

@@ -468,10 +468,10 @@ int maus_jacobi_check_run(maus_ctx* c, int count, const double* shift, const dou
     if (ensure_scratch(c, sizeof(c128) * n)) return -1;
     c128* dA = (c128*)c->scratch;
     hipLaunchKernelGGL(diag_kernel, dim3((n + 255) / 256), dim3(256), 0, c->st, c->A, n, dA);
-    HIPCHK(c, hipMemcpyAsync(c->d_c1, shift, sizeof(c128) * count, hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipMemcpyAsync(c->d_r1, psi, sizeof(double) * count, hipMemcpyHostToDevice, c->st));
+    if (maus_h2d(c, c->d_c1, shift, sizeof(c128) * count, c->st)) return -1;
+    if (maus_h2d(c, c->d_r1, psi, sizeof(double) * count, c->st)) return -1;
     hipLaunchKernelGGL(jacobi_check_kernel, dim3(count), dim3(GT), 0, c->st, dA, n, c->d_c1, c->d_r1, c->d_i1);
-    HIPCHK(c, hipMemcpyAsync(ok, c->d_i1, sizeof(int) * count, hipMemcpyDeviceToHost, c->st));
+    if (maus_d2h(c, ok, c->d_i1, sizeof(int) * count, c->st)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->st));
     return 0;
 }
@@ -504,9 +504,9 @@ int maus_gmres_run(maus_ctx* c, const int* slots, int count, const double* shift
     int* jac = (int*)(base + o_j); int* outs = (int*)(base + o_o);
     a.Hd = Hdense; a.ldh = ldh; a.strideH = strideH;
     a.shift = c->d_c1; a.psi = c->d_r1; a.jac = jac; a.X = c->X; a.ldx = c->ldp; a.slots = c->d_slots; a.bvec = c->b; a.rhs_mode = rhs_mode;
-    HIPCHK(c, hipMemcpyAsync(c->d_c1, shift, sizeof(c128) * count, hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipMemcpyAsync(c->d_r1, psi, sizeof(double) * count, hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipMemcpyAsync(jac, use_jacobi, sizeof(int) * count, hipMemcpyHostToDevice, c->st));
+    if (maus_h2d(c, c->d_c1, shift, sizeof(c128) * count, c->st)) return -1;
+    if (maus_h2d(c, c->d_r1, psi, sizeof(double) * count, c->st)) return -1;
+    if (maus_h2d(c, jac, use_jacobi, sizeof(int) * count, c->st)) return -1;
     hipLaunchKernelGGL(diag_kernel, dim3((n + 255) / 256), dim3(256), 0, c->st, c->A, n, (c128*)(base + o_d));
     if (Hdense) hipLaunchKernelGGL(jacobi_gate_dense_kernel, dim3(count), dim3(GT), 0, c->st, a, jac);
     hipLaunchKernelGGL(gmres_init_kernel, dim3(count), dim3(GT), 0, c->st, a);
@@ -514,7 +514,7 @@ int maus_gmres_run(maus_ctx* c, const int* slots, int count, const double* shift
     int h_nact = 0;
     for (long tick = 0; tick < max_ticks; ++tick) {
         hipLaunchKernelGGL(gmres_compact_kernel, dim3(1), dim3(1024), 0, c->st, a.st, count, (int)rows_per, R, act, zrow, nact);
-        HIPCHK(c, hipMemcpyAsync(&h_nact, nact, sizeof(int), hipMemcpyDeviceToHost, c->st));
+        if (maus_d2h(c, &h_nact, nact, sizeof(int), c->st)) return -1;
         HIPCHK(c, hipStreamSynchronize(c->st));
         if (h_nact <= 0) break;
         if (Hdense) {
@@ -529,10 +529,10 @@ int maus_gmres_run(maus_ctx* c, const int* slots, int count, const double* shift
           else hipLaunchKernelGGL((gmres_post_kernel<32>), dim3(h_nact), dim3(GT), 0, c->st, a, act); }
     }
     hipLaunchKernelGGL(gmres_finish_kernel, dim3(count), dim3(GT), 0, c->st, a, c->W, c->ldp, outs, outs + count, outs + 2 * count);
-    HIPCHK(c, hipMemcpyAsync(info_out, outs, sizeof(int) * count, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(inner_out, outs + count, sizeof(int) * count, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(status, outs + 2 * count, sizeof(int) * count, hipMemcpyDeviceToHost, c->st));
-    if (jacobi_out) HIPCHK(c, hipMemcpyAsync(jacobi_out, jac, sizeof(int) * count, hipMemcpyDeviceToHost, c->st));
+    if (maus_d2h(c, info_out, outs, sizeof(int) * count, c->st)) return -1;
+    if (maus_d2h(c, inner_out, outs + count, sizeof(int) * count, c->st)) return -1;
+    if (maus_d2h(c, status, outs + 2 * count, sizeof(int) * count, c->st)) return -1;
+    if (jacobi_out) { if (maus_d2h(c, jacobi_out, jac, sizeof(int) * count, c->st)) return -1; }
     HIPCHK(c, hipStreamSynchronize(c->st));
     HIPCHK(c, hipGetLastError());
     return 0;

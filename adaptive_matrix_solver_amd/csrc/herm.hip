@@ -365,8 +365,8 @@ int maus_herm_tridiag(maus_ctx* c, double* d_out, double* e_out) {
         }
         err = hipGetLastError();
     }
-    if (err == hipSuccess) err = hipMemcpyAsync(d_out, d, sizeof(double) * n, hipMemcpyDeviceToHost, st);
-    if (err == hipSuccess && n > 1) err = hipMemcpyAsync(e_out, e, sizeof(double) * (n - 1), hipMemcpyDeviceToHost, st);
+    if (err == hipSuccess && maus_stage_d2h(c, d_out, d, sizeof(double) * n, st)) return -1;
+    if (err == hipSuccess && n > 1 && maus_stage_d2h(c, e_out, e, sizeof(double) * (n - 1), st)) return -1;
     if (err == hipSuccess) err = hipStreamSynchronize(st);
     if (err == hipSuccess) err = hipGetLastError();
     clk.lap("tridiag: enqueue + kernels");
@@ -396,7 +396,8 @@ int maus_herm_backtransform(maus_ctx* c, const double* z_real, int col_major) {
 #undef HERM_ALLOC
     clk.lap("backtransform: allocations");
     hipStream_t st = c->st;
-    hipError_t err = hipMemcpyAsync(Zr, z_real, sizeof(double) * nn, hipMemcpyHostToDevice, st);
+    hipError_t err = hipSuccess;
+    if (maus_stage_h2d(c, Zr, z_real, sizeof(double) * nn, st)) return -1;      // (the caller's Z is freed right after: see capi.hip on pinned staging)
     if (clk.on) { (void)hipStreamSynchronize(st); clk.lap("backtransform: upload of Z"); }
     if (err == hipSuccess) {
         if (col_major) hipLaunchKernelGGL(herm_transpose_to_complex_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, st, Zr, n, c->V);

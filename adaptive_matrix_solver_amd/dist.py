@@ -250,11 +250,8 @@ class PopulationComm:
         except Exception:
             yield
             return
-        try:
-            ncpu = len(os.sched_getaffinity(0))
-        except Exception:
-            ncpu = os.cpu_count() or 1
-        with threadpool_limits(limits=max(1, ncpu)):
+        from .engine import cpu_allowance
+        with threadpool_limits(limits=cpu_allowance()):       # (not the visible cores: engine.cap_blas_threads)
             yield
 
 

@@ -80,6 +80,47 @@ class _AsyncStreamAdvance:
         self.thread.join()
 
 
+def cpu_allowance() -> int:
+    """CPUs this process may actually use: the affinity mask, cut down by the cgroup's CPU quota (cpu.max) when there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+_blas_cap_done = False
+
+
+def cap_blas_threads() -> None:
+    """Keep the host BLAS pools within the CPUs the process is allowed (once per process; MAUS_BLAS_THREADS=0 leaves them
+    alone, =k sets k).  OpenBLAS starts one thread per visible core -- 256 on an MI355X host -- and its workers spin for a
+    while after every parallel call; under a 16-CPU container quota the orchestration thread then loses the CPU for 50-90 ms
+    at a time, at random inside a loop body or inside a library call that is waiting for the GPU (BASELINE configs[2]: one
+    17 ms loop body in ten took 90 ms; tools/body_probe.py).  The loop bodies only use BLAS for dot products of length n."""
+    global _blas_cap_done
+    if _blas_cap_done:
+        return
+    _blas_cap_done = True
+    env = os.environ.get("MAUS_BLAS_THREADS", "auto")
+    if env == "0":
+        return
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+        limit = int(env) if env not in ("auto", "") else cpu_allowance()
+        if any(m.get("num_threads", 1) > limit for m in threadpool_info()):
+            threadpool_limits(limits=limit)          # not used as a context manager: stays in force
+    except Exception:
+        pass
+
+
 EIGH_DEVICE_MIN = 1536                     # eigh_mode='auto': device reduction / back-transformation from this order up
 COND_THRESHOLDS = (1e6, 1e12, 1e15)        # AMS:401, 407-416: the only places the condition number is used
 COND_GUARD = 30.0                          # an estimate this close (either side) to a threshold is not trusted
@@ -179,6 +220,7 @@ class DeviceEngine:
     def __init__(self, device: int = 0, pert_mode: str = "auto", gmres_compat: str = "rtol",
                  comm=None, ctx=None, eigh_mode: str = "auto"):
         self.ctx = ctx if ctx is not None else _cabi.Context(device)
+        cap_blas_threads()
         # Hermitian eigendecomposition (AMS:161), once per matrix: 'host' = scipy.linalg.eigh, the reference's call, (lambda, V)
         # bit-identical to its; 'device' = reduction and back-transformation on the GPU, the tridiagonal eigenproblem by LAPACK
         # dstemr on the host (csrc/herm.hip); 'auto' = device from n = EIGH_DEVICE_MIN up.  MAUS_EIGH overrides.

@@ -169,7 +169,10 @@ def run_other_config(args):
     P = cfg["pop"] if args.pop is None else args.pop
     kind = cfg["kind"]
     steps_k = args.steps if "--steps" in sys.argv else cfg["steps"]
-    warm_k = args.warmup if "--warmup" in sys.argv else 1
+    # Hermitian shortcut: every candidate converges in its first step, so a warm-up body on a scratch solver warms nothing
+    # that the timed solver meets again -- and a second solver on the same engine would put a host comparison of two copies of
+    # the matrix (is the resident decomposition still this matrix's?  ~100 ms at n = 8192) into the first timed loop body
+    warm_k = args.warmup if "--warmup" in sys.argv else (0 if kind == "herm" else 1)
     b = None
     if kind == "eig":
         A, PT = scenarios.ginibre(n, n), ProblemType.EIGENVALUE
@@ -205,8 +208,11 @@ def run_other_config(args):
     ctx.sync()
     t_warm = time.perf_counter() - t0                  # c4: contains the once-per-matrix eigh unless the diagnostics already did it
     diag = dict(scratch.diag_info)
-    del scratch
-    solver = build(engine=eng, diag=diag)
+    if warm_k == 0:
+        solver = scratch                               # as a user runs it: one solver, construction outside the metric
+    else:
+        del scratch
+        solver = build(engine=eng, diag=diag)
     gm = {"calls": 0, "cands": 0, "inner": 0}
     if kind == "lin":
         _g = ctx.gmres

@@ -33,6 +33,21 @@ def body(it):
     return s.loop_body(it)
 
 
+if os.environ.get("SPLIT_SYNC"):                 # bill pending device work to a sync in front of every read-back, not to the read-back
+    _ctx = s.engine.ctx; _pg = _ctx.pop_get; _sy = _ctx.sync
+    def sync_before_pop_get(): _sy()
+    def pop_get_split(*a, **k):
+        sync_before_pop_get()
+        return _pg(*a, **k)
+    _ctx.pop_get = pop_get_split
+    for _nm in ("hist_append", "herm_match", "residual", "pop_put", "gram"):
+        def _mk(nm, real):
+            def f(*a, **k):
+                r = real(*a, **k); t0 = time.perf_counter(); _sy(); dt = (time.perf_counter() - t0) * 1e3
+                if dt > 0.5: print(f"[split] device work left behind by {nm}: {dt:.2f} ms")
+                return r
+            return f
+        setattr(_ctx, _nm, _mk(_nm, getattr(_ctx, _nm)))
 if cfg != "c4":
     body(1)
 s.engine.ctx.sync()
