@@ -15,7 +15,11 @@
  *    convention, AMS:59 -> LinAlgError; -1 non-finite input matrix/rhs, -2
  *    non-finite result, AMS:94-95 -> ValueError), so the Python retry ladder
  *    (AMS:98-104) is reproduced exactly.
- *  - Host buffers are caller-owned.  Device buffers are owned by the context.
+ *  - Host buffers are caller-owned and are only read / written by plain memcpy
+ *    while a call is in progress: every transfer goes through a pinned buffer
+ *    of the context (a caller array handed to the runtime would stay
+ *    registered with the driver and stall the GPU queues when the caller frees
+ *    it).  Device buffers are owned by the context.
  *  - One context per GPU, not thread-safe; calls are synchronous as seen by the
  *    caller (work is enqueued on the context's own HIP stream and joined before
  *    results are returned).
