@@ -12,7 +12,7 @@ import glob
 import re
 import sys
 
-LU_ZGEMM = re.compile(r"zgemm(3m_dma)?_kernel<[^>]*, true>")
+LU_ZGEMM = re.compile(r"zgemm_kernel<[^>]*, true>|zgemm3m_dma_kernel<\d+, \d+, \d+, \d+, true,")       # TILED = true: the LU's instantiations
 trace = [tuple(int(x) for x in line.split()) for line in open(sys.argv[1]) if line.strip()]
 for f in glob.glob(sys.argv[2] + "/**/*kernel_trace.csv", recursive=True):
     rows = [r for r in csv.DictReader(open(f)) if LU_ZGEMM.search(r["Kernel_Name"])]      # TILED = true: the LU's instantiations
