@@ -218,7 +218,7 @@ int maus_ctx_destroy(maus_ctx* c) {
     (void)hipStreamSynchronize(c->st);
     (void)maus_comm_destroy(c);
     void* ptrs[] = {c->A, c->b, c->V, c->X, c->U, c->W, c->Y, c->d_slots, c->d_i1, c->d_i2, c->d_c1, c->d_c2, c->d_r1, c->d_r2,
-                    c->H, c->ipiv, c->perm, c->mw_sync, c->info, c->flags, c->Upert, c->scratch, c->hq, c->htau};
+                    c->H, c->ipiv, c->perm, c->mw_sync, c->info, c->flags, c->Upert, c->scratch, c->hq, c->htau, c->hz};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pin_small) (void)hipHostFree(c->pin_small);
@@ -273,6 +273,7 @@ int maus_set_matrix(maus_ctx* c, const double* a, int rows, int cols) {
         c->rows = rows; c->cols = cols;
     }
     if (c->hq) { (void)hipFree(c->hq); c->hq = nullptr; } if (c->htau) { (void)hipFree(c->htau); c->htau = nullptr; } c->hqn = 0;   // reflectors of the previous matrix
+    if (c->hz) { (void)hipFree(c->hz); c->hz = nullptr; c->hzn = 0; }
     return maus_stage_h2d(c, c->A, a, sizeof(c128) * (size_t)rows * cols, c->st);
 }
 

@@ -54,6 +54,7 @@ struct maus_ctx {
     c128* b = nullptr; int bn = 0;                  // rhs
     c128* V = nullptr; int vn = 0;                  // eigenvectors (Hermitian shortcut)
     c128* hq = nullptr; c128* htau = nullptr; int hqn = 0;   // Householder reflectors of maus_herm_tridiag, until the back-transformation (herm.hip)
+    double* hz = nullptr; int hzn = 0;                       // eigenvectors of T (maus_herm_tridiag_eig), until the back-transformation
     int cap = 0; long ldp = 0;                      // population
     c128 *X = nullptr, *U = nullptr, *W = nullptr, *Y = nullptr;
     // per-call scalar staging (device), sized for `scal_cap` candidates

@@ -284,6 +284,107 @@ herm_transpose_to_complex_kernel(const double* __restrict__ Zt, int n, c128* __r
 extern "C" {
 
 // MAUS_HERM_TIMING=1: host wall time of the phases on stderr (allocation of GiB-sized buffers is not free)
+// ---- the real symmetric tridiagonal eigenproblem on the device (r03) ---------------------------------------------------------
+// Eigenvalue i by bisection on the Sturm count (one thread per eigenvalue; LAPACK dstebz's recurrence and pivot guard), its
+// eigenvector from the twisted factorisation of T - lambda I (Fernando / Parlett-Dhillon, the getvec step of dstemr): a forward
+// L D+ L^T and a backward U D- U^T sweep, the twist at the index of the smallest |gamma_k| = |D+_k + D-_k - (d_k - lambda)|,
+// z_r = 1 and two two-term recurrences away from it.  O(n) per vector, no reorthogonalisation: for an eigenvalue that the
+// bisection knows to eps ||T|| the vector is off by eps ||T|| / gap, so the caller (engine.device_eigh) accepts the result only
+// when the smallest gap is large against eps ||T|| and the residuals measured here are at rounding level, and otherwise takes
+// the host's dstemr.  Arrays are [k][i] (component k of vector i): every access is coalesced over the eigenvalue index.
+__global__ void __launch_bounds__(256)
+tri_bisect_kernel(const double* __restrict__ d, const double* __restrict__ e2, int n, double gl, double gu, double pivmin,
+                  double* __restrict__ w)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double lo = gl, hi = gu;
+    for (int it = 0; it < 1100; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (!(mid > lo && mid < hi)) break;                       // the interval is one ulp wide
+        double q = d[0] - mid;
+        if (fabs(q) < pivmin) q = -pivmin;
+        int cnt = q < 0.0;
+        for (int k = 1; k < n; ++k) {
+            q = (d[k] - mid) - e2[k - 1] / q;
+            if (fabs(q) < pivmin) q = -pivmin;
+            cnt += q < 0.0;
+        }
+        if (cnt > i) hi = mid; else lo = mid;                     // cnt = number of eigenvalues below mid
+    }
+    w[i] = 0.5 * (lo + hi);
+}
+
+__global__ void __launch_bounds__(256)
+tri_twisted_kernel(const double* __restrict__ d, const double* __restrict__ e, int n, const double* __restrict__ w, double tiny,
+                   double* __restrict__ Z, double* __restrict__ B, double* __restrict__ nrm2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long ld = n;
+    const double lam = w[i];
+    auto guard = [tiny](double x) { return fabs(x) < tiny ? copysign(tiny, x) : x; };
+    double dp = guard(d[0] - lam);                                // forward: D+_k into Z[k][i]
+    Z[i] = dp;
+    for (int k = 0; k + 1 < n; ++k) {
+        const double l = e[k] / dp;
+        dp = guard((d[k + 1] - lam) - l * e[k]);
+        Z[(long)(k + 1) * ld + i] = dp;
+    }
+    double dm = guard(d[n - 1] - lam);                            // backward: D-_k into B[k][i]; the twist index on the way
+    B[(long)(n - 1) * ld + i] = dm;
+    double best = fabs(dp + dm - (d[n - 1] - lam));
+    int r = n - 1;
+    for (int k = n - 2; k >= 0; --k) {
+        const double u = e[k] / dm;
+        dm = guard((d[k] - lam) - u * e[k]);
+        B[(long)k * ld + i] = dm;
+        const double g = fabs(Z[(long)k * ld + i] + dm - (d[k] - lam));
+        if (g < best) { best = g; r = k; }
+    }
+    double ss = 1.0, zk = 1.0;                                    // z_r = 1;  z_k = -(e_k / D+_k) z_{k+1} below the twist
+    for (int k = r - 1; k >= 0; --k) {
+        zk = -(e[k] / Z[(long)k * ld + i]) * zk;
+        Z[(long)k * ld + i] = zk;
+        ss = fma(zk, zk, ss);
+    }
+    zk = 1.0;                                                     // z_{k+1} = -(e_k / D-_{k+1}) z_k above it
+    for (int k = r; k + 1 < n; ++k) {
+        zk = -(e[k] / B[(long)(k + 1) * ld + i]) * zk;
+        Z[(long)(k + 1) * ld + i] = zk;
+        ss = fma(zk, zk, ss);
+    }
+    Z[(long)r * ld + i] = 1.0;
+    nrm2[i] = ss;
+}
+
+// Z[k][i] /= ||z_i||, then res[i] = max_k |(T z_i - lambda_i z_i)_k| of the normalised vector
+__global__ void __launch_bounds__(256)
+tri_scale_kernel(double* __restrict__ Z, int n, const double* __restrict__ nrm2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (i < n) Z[(long)k * n + i] *= 1.0 / sqrt(nrm2[i]);
+}
+
+__global__ void __launch_bounds__(256)
+tri_resid_kernel(const double* __restrict__ d, const double* __restrict__ e, int n, const double* __restrict__ w,
+                 const double* __restrict__ Z, double* __restrict__ res)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double lam = w[i];
+    double zm = 0.0, z0 = Z[i], worst = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double zp = (k + 1 < n) ? Z[(long)(k + 1) * n + i] : 0.0;
+        double rk = (d[k] - lam) * z0;
+        if (k > 0) rk = fma(e[k - 1], zm, rk);
+        if (k + 1 < n) rk = fma(e[k], zp, rk);
+        worst = fmax(worst, fabs(rk));
+        zm = z0; z0 = zp;
+    }
+    res[i] = worst;
+}
+
 struct HermClock {
     bool on; std::chrono::steady_clock::time_point t;
     HermClock() : on(getenv("MAUS_HERM_TIMING") && atoi(getenv("MAUS_HERM_TIMING"))), t(std::chrono::steady_clock::now()) {}
@@ -296,6 +397,7 @@ struct HermClock {
 };
 
 static void herm_free(maus_ctx* c) {
+    if (c->hz) { (void)hipFree(c->hz); c->hz = nullptr; c->hzn = 0; }
     if (c->hq) { (void)hipFree(c->hq); c->hq = nullptr; }
     if (c->htau) { (void)hipFree(c->htau); c->htau = nullptr; }
     c->hqn = 0;
@@ -365,8 +467,8 @@ int maus_herm_tridiag(maus_ctx* c, double* d_out, double* e_out) {
         }
         err = hipGetLastError();
     }
-    if (err == hipSuccess && maus_stage_d2h(c, d_out, d, sizeof(double) * n, st)) return -1;
-    if (err == hipSuccess && n > 1 && maus_stage_d2h(c, e_out, e, sizeof(double) * (n - 1), st)) return -1;
+    if (err == hipSuccess && (maus_stage_d2h(c, d_out, d, sizeof(double) * n, st)
+                              || (n > 1 && maus_stage_d2h(c, e_out, e, sizeof(double) * (n - 1), st)))) { cleanup(); herm_free(c); return -1; }
     if (err == hipSuccess) err = hipStreamSynchronize(st);
     if (err == hipSuccess) err = hipGetLastError();
     clk.lap("tridiag: enqueue + kernels");
@@ -379,7 +481,9 @@ int maus_herm_tridiag(maus_ctx* c, double* d_out, double* e_out) {
 int maus_herm_backtransform(maus_ctx* c, const double* z_real, int col_major) {
     const int n = c->rows;
     if (!c->hq || c->hqn != n || n != c->cols) FAIL(c, "maus_herm_backtransform: no reflectors for this matrix (maus_herm_tridiag first)");
-    if (!z_real) FAIL(c, "maus_herm_backtransform: null input");
+    // z_real == NULL: the eigenvectors of T that maus_herm_tridiag_eig left on the device
+    if (!z_real && (!c->hz || c->hzn != n)) FAIL(c, "maus_herm_backtransform: null input and no eigenvectors of T on the device (maus_herm_tridiag_eig)");
+    if (z_real && c->hz) { (void)hipFree(c->hz); c->hz = nullptr; c->hzn = 0; }
     HermClock clk;
     const size_t nn = (size_t)n * n;
     if (c->vn != n) { if (c->V) (void)hipFree(c->V); c->V = nullptr; c->vn = 0; HIPCHK(c, hipMalloc((void**)&c->V, sizeof(c128) * nn)); c->vn = n; }
@@ -387,7 +491,8 @@ int maus_herm_backtransform(maus_ctx* c, const double* z_real, int col_major) {
     auto cleanup = [&]() { void* ps[] = {Zr, Vt, G, T, X, Y}; for (void* p : ps) if (p) (void)hipFree(p); };
 #define HERM_ALLOC(ptr, bytes) do { if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { (void)hipGetLastError(); cleanup(); \
         FAIL(c, "maus_herm_backtransform: out of device memory"); } } while (0)
-    HERM_ALLOC(Zr, sizeof(double) * nn);
+    if (z_real) HERM_ALLOC(Zr, sizeof(double) * nn);
+    else { Zr = c->hz; c->hz = nullptr; c->hzn = 0; }          // ownership moves here: freed with the other temporaries
     HERM_ALLOC(Vt, sizeof(c128) * (size_t)HNB * n);
     HERM_ALLOC(G, sizeof(c128) * HNB * HNB);
     HERM_ALLOC(T, sizeof(c128) * HNB * HNB);
@@ -397,7 +502,7 @@ int maus_herm_backtransform(maus_ctx* c, const double* z_real, int col_major) {
     clk.lap("backtransform: allocations");
     hipStream_t st = c->st;
     hipError_t err = hipSuccess;
-    if (maus_stage_h2d(c, Zr, z_real, sizeof(double) * nn, st)) return -1;      // (the caller's Z is freed right after: see capi.hip on pinned staging)
+    if (z_real && maus_stage_h2d(c, Zr, z_real, sizeof(double) * nn, st)) { cleanup(); return -1; }   // (the caller's Z is freed right after: see capi.hip on pinned staging)
     if (clk.on) { (void)hipStreamSynchronize(st); clk.lap("backtransform: upload of Z"); }
     if (err == hipSuccess) {
         if (col_major) hipLaunchKernelGGL(herm_transpose_to_complex_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, st, Zr, n, c->V);
@@ -432,3 +537,68 @@ int maus_herm_backtransform(maus_ctx* c, const double* z_real, int col_major) {
 }
 
 }  // extern "C"
+
+// Eigenvalues (ascending, to the host) and eigenvectors (left on the device for maus_herm_backtransform(ctx, NULL, 0)) of the
+// real symmetric tridiagonal matrix (d, e).  diag_out[0] = smallest gap between neighbouring eigenvalues / ||T||,
+// diag_out[1] = largest residual component max_k |(T z - lambda z)_k| over all vectors / ||T||, diag_out[2] = ||T|| (the
+// Gershgorin radius); the caller decides from them whether to keep the result (see the kernels above).
+int maus_herm_tridiag_eig(maus_ctx* c, const double* d_host, const double* e_host, int n, double* w_out, double* diag_out) {
+    if (!d_host || (!e_host && n > 1) || !w_out || !diag_out || n < 1) FAIL(c, "maus_herm_tridiag_eig: bad arguments");
+    HermClock clk;
+    if (c->hz) { (void)hipFree(c->hz); c->hz = nullptr; c->hzn = 0; }
+    // Gershgorin interval and the scale of the problem (host: 2 n numbers)
+    double gl = d_host[0], gu = d_host[0], emax = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double a = (k > 0 ? fabs(e_host[k - 1]) : 0.0) + (k + 1 < n ? fabs(e_host[k]) : 0.0);
+        gl = std::min(gl, d_host[k] - a); gu = std::max(gu, d_host[k] + a);
+        if (k + 1 < n) emax = std::max(emax, fabs(e_host[k]));
+    }
+    const double tnorm = std::max(fabs(gl), fabs(gu));
+    if (!(tnorm < 1e150) || !(tnorm == tnorm)) FAIL(c, "maus_herm_tridiag_eig: the matrix is not finite or too large (scale it first)");
+    const double eps = 2.220446049250313e-16, safmin = 2.2250738585072014e-308;
+    const double pivmin = safmin * std::max(1.0, emax * emax);
+    gl -= 2.0 * eps * n * tnorm + 2.0 * pivmin; gu += 2.0 * eps * n * tnorm + 2.0 * pivmin;
+    std::vector<double> e2(std::max(1, n));
+    for (int k = 0; k + 1 < n; ++k) e2[k] = e_host[k] * e_host[k];
+    const size_t nn = (size_t)n * n;
+    double *dd = nullptr, *de = nullptr, *de2 = nullptr, *dw = nullptr, *dn = nullptr, *dr = nullptr, *Z = nullptr, *B = nullptr;
+    auto cleanup = [&]() { void* ps[] = {dd, de, de2, dw, dn, dr, Z, B}; for (void* p : ps) if (p) (void)hipFree(p); };
+#define TRI_ALLOC(ptr, bytes) do { if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { (void)hipGetLastError(); cleanup(); \
+        FAIL(c, "maus_herm_tridiag_eig: out of device memory"); } } while (0)
+    TRI_ALLOC(dd, sizeof(double) * n); TRI_ALLOC(de, sizeof(double) * n); TRI_ALLOC(de2, sizeof(double) * n);
+    TRI_ALLOC(dw, sizeof(double) * n); TRI_ALLOC(dn, sizeof(double) * n); TRI_ALLOC(dr, sizeof(double) * n);
+    TRI_ALLOC(Z, sizeof(double) * nn); TRI_ALLOC(B, sizeof(double) * nn);
+#undef TRI_ALLOC
+    hipStream_t st = c->st;
+    std::vector<double> ez(n, 0.0);
+    for (int k = 0; k + 1 < n; ++k) ez[k] = e_host[k];
+    if (maus_stage_h2d(c, dd, d_host, sizeof(double) * n, st) || maus_stage_h2d(c, de, ez.data(), sizeof(double) * n, st)
+        || maus_stage_h2d(c, de2, e2.data(), sizeof(double) * n, st)) { cleanup(); return -1; }
+    const dim3 g1((n + 255) / 256), b1(256);
+    hipLaunchKernelGGL(tri_bisect_kernel, g1, b1, 0, st, dd, de2, n, gl, gu, pivmin, dw);
+    if (clk.on) { (void)hipStreamSynchronize(st); clk.lap("tridiag eig: bisection"); }
+    hipLaunchKernelGGL(tri_twisted_kernel, g1, b1, 0, st, dd, de, n, dw, eps * std::max(tnorm, safmin / eps), Z, B, dn);
+    hipLaunchKernelGGL(tri_scale_kernel, dim3((n + 255) / 256, n), b1, 0, st, Z, n, dn);
+    hipLaunchKernelGGL(tri_resid_kernel, g1, b1, 0, st, dd, de, n, dw, Z, dr);
+    std::vector<double> res(n);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess && (maus_stage_d2h(c, w_out, dw, sizeof(double) * n, st) || maus_stage_d2h(c, res.data(), dr, sizeof(double) * n, st))) { cleanup(); return -1; }
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    if (err == hipSuccess) err = hipGetLastError();
+    clk.lap("tridiag eig: vectors + checks");
+    if (err != hipSuccess) { cleanup(); char buf[256]; snprintf(buf, sizeof buf, "maus_herm_tridiag_eig failed: %s", hipGetErrorString(err)); c->err = buf; return -1; }
+    double gap = (n > 1) ? 1e300 : 1.0, rmax = 0.0;
+    bool finite = true;
+    for (int k = 0; k < n; ++k) {
+        if (!(res[k] == res[k]) || !(w_out[k] == w_out[k])) finite = false;
+        rmax = std::max(rmax, res[k]);
+        if (k > 0) gap = std::min(gap, w_out[k] - w_out[k - 1]);
+    }
+    const double scale = tnorm > 0.0 ? tnorm : 1.0;
+    diag_out[0] = (n > 1) ? gap / scale : 1.0;
+    diag_out[1] = finite ? rmax / scale : 1e300;
+    diag_out[2] = tnorm;
+    c->hz = Z; c->hzn = n; Z = nullptr;                              // kept for the back-transformation
+    cleanup();
+    return 0;
+}

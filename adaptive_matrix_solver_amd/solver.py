@@ -542,7 +542,13 @@ class MAUS_Solver:
                 and matrix.shape[0] == matrix.shape[1] and matrix.size > 0):
             try:
                 cond_num_val = None
-                if getattr(self, "_cond_device", None) is not None and matrix.shape[0] > self._cond_exact_max:
+                # A Hermitian eigenproblem whose decomposition runs on the device (1.1 s at n = 8192, and the shortcut of AMS:161
+                # needs it anyway) takes its condition number from the eigenvalues at once: the estimator's six LU
+                # factorisations would cost four times as much (r03)
+                herm_first = (diag_info["is_hermitian"] and self.problem_type == ProblemType.EIGENVALUE
+                              and getattr(self, "_cond_device", None) is not None and matrix.shape[0] > self._cond_exact_max
+                              and self.engine.use_device_eigh(matrix.shape[0]) and np.all(np.isfinite(matrix)))
+                if not herm_first and getattr(self, "_cond_device", None) is not None and matrix.shape[0] > self._cond_exact_max:
                     from .engine import estimate_condition_number
                     kappa, trusted = estimate_condition_number(matrix, device=self._cond_device)
                     diag_info["condition_number_estimate"] = kappa
@@ -551,8 +557,8 @@ class MAUS_Solver:
                 diag_info["condition_number_is_estimate"] = cond_num_val is not None
                 if (cond_num_val is None and diag_info["is_hermitian"] and self.problem_type == ProblemType.EIGENVALUE
                         and getattr(self, "_cond_device", None) is not None and matrix.shape[0] > self._cond_exact_max):
-                    # the estimate fell into the guard band of a threshold.  A Hermitian eigenproblem decomposes the matrix
-                    # anyway (AMS:161, once per matrix here), and sigma_i = |lambda_i|: take the 2-norm condition number
+                    # (or, host decomposition: the estimate fell into the guard band of a threshold.)  A Hermitian eigenproblem
+                    # decomposes the matrix anyway (AMS:161, once per matrix here), and sigma_i = |lambda_i|: take the 2-norm condition number
                     # from the eigenvalues and hand the decomposition to the engine instead of running an SVD on top
                     # (44 s + 70 s at n = 8192, profiles/r02_c4_hermitian_8192_end_to_end.txt)
                     import scipy.linalg as sla

@@ -196,8 +196,15 @@ int maus_herm_match(maus_ctx* ctx, const int* slots, int count, int32_t* idx_out
  *   maus_herm_tridiag        A = Q T Q^H of the context's (Hermitian) matrix, zhetrd('L') semantics and reflector
  *                            conventions; d_out[n] / e_out[n-1]: diagonal / subdiagonal of the real T.  The reflectors stay
  *                            on the device until the back-transformation.
- *   (caller)                 eigenpairs (lambda, Z) of T -- scipy.linalg.eigh_tridiagonal, the kernel zheevr uses.
- *   maus_herm_backtransform  V = Q Z (zunmtr semantics) from the real eigenvectors of T -- z_real[n][n] row-major (column k = k-th
+ *   maus_herm_tridiag_eig    eigenpairs (lambda, Z) of T on the device: bisection on the Sturm count, eigenvectors from the
+ *                            twisted factorisation of T - lambda I (the getvec step of dstemr), no reorthogonalisation.
+ *                            w_out[n] ascending; Z stays on the device for maus_herm_backtransform(ctx, NULL, 0).
+ *                            diag_out[3] = {smallest eigenvalue gap / ||T||, largest residual component / ||T||, ||T||}: the
+ *                            caller keeps the result only for well separated spectra with rounding-level residuals and
+ *                            otherwise solves T on the host (scipy.linalg.eigh_tridiagonal = dstemr, the kernel zheevr uses)
+ *                            and passes its Z.
+ *   maus_herm_backtransform  V = Q Z (zunmtr semantics) from the real eigenvectors of T -- NULL (the device-resident Z of
+ *                            maus_herm_tridiag_eig) or z_real[n][n] row-major (column k = k-th
  *                            eigenvector), or with col_major != 0 column-major as LAPACK returns them -- into the context's
  *                            eigenvector matrix, as if set by maus_set_eigvecs.
  * The first row of V is real (Q e_1 = e_1), LAPACK's phase convention. */
@@ -205,6 +212,7 @@ int maus_herm_tridiag(maus_ctx* ctx, double* d_out, double* e_out);
 /* the context's eigenvector matrix back on the host (v_out[n][n] complex128, row-major; tests, users of evolve()'s report) */
 int maus_get_eigvecs(maus_ctx* ctx, double* v_c128_out, int n);
 int maus_herm_backtransform(maus_ctx* ctx, const double* z_real, int col_major);
+int maus_herm_tridiag_eig(maus_ctx* ctx, const double* d, const double* e, int n, double* w_out, double* diag_out);
 
 /* Gram block of candidate vectors for the distinctness / redundancy tests      AMS:432-437, 443-451, 509-520:
  * out[i*count + j] = vdot(x_i, x_j) = sum_k conj(x_i[k]) x_j[k] over the first `len` entries of rows `slots`

@@ -186,3 +186,108 @@ def test_degenerate_and_scaled_inputs(ctx, kind):
     assert np.linalg.norm(A @ V - V * w[None, :]) <= 1e-12 * scale * n
     assert np.linalg.norm(V.conj().T @ V - np.eye(n)) <= 1e-12 * n
     assert np.abs(V[0].imag).max() == 0.0
+
+
+# ---- the tridiagonal eigenproblem itself on the device (maus_herm_tridiag_eig: bisection + twisted factorisation) --------------
+@pytest.mark.parametrize("n", [2, 3, 64, 257, 1000, 2048])
+def test_tridiagonal_eigenproblem_on_the_device(ctx, n):
+    """Eigenvalues against LAPACK's to a few ulps of ||T||; the vectors through the back-transformation diagonalise A with
+    residuals at rounding level and are orthogonal to eps ||T|| / gap; the function's own diagnostics say so."""
+    from adaptive_matrix_solver_amd.engine import TRIDIAG_MAX_RESID, TRIDIAG_MIN_GAP
+    A = scenarios.hermitian(n, 4000 + n)
+    anorm = np.linalg.norm(A, 2)
+    ctx.set_matrix(A)
+    d, e = ctx.herm_tridiag()
+    # LAPACK's own solvers differ from each other by 7-20 ulps of ||T|| on such matrices (dstebz, the same bisection, against
+    # dstemr); the device values sit within half an ulp of dstebz's
+    wl = sla.eigh_tridiagonal(d, e, eigvals_only=True, lapack_driver="stemr")
+    wz = sla.eigh_tridiagonal(d, e, eigvals_only=True, lapack_driver="stebz")
+    w, (gap, resid, tnorm) = ctx.herm_tridiag_eig(d, e)
+    assert np.all(np.diff(w) >= 0)
+    assert np.abs(w - wl).max() <= 64 * EPS * tnorm, np.abs(w - wl).max() / (EPS * tnorm)
+    assert np.abs(w - wz).max() <= 4 * EPS * tnorm, np.abs(w - wz).max() / (EPS * tnorm)
+    assert gap >= TRIDIAG_MIN_GAP and resid <= TRIDIAG_MAX_RESID, (gap, resid)
+    assert abs(gap - np.diff(wl).min() / tnorm) <= 1e-3 * gap + 16 * EPS
+    ctx.herm_backtransform(None)                                 # the Z the call left on the device
+    V = ctx.get_eigvecs()
+    assert np.abs(A @ V - V * w[None, :]).max() <= 60 * n * EPS * anorm
+    orth = np.abs(V.conj().T @ V - np.eye(n)).max()
+    assert orth <= max(50 * EPS / gap, 1e3 * EPS), (orth, gap)    # eps ||T|| / gap, the bound the acceptance rule relies on
+    assert np.abs(V[0].imag).max() == 0.0                        # LAPACK's phase convention survives (Q e_1 = e_1)
+    # the same columns as LAPACK's up to sign
+    Vl = sla.eigh(A)[1]
+    assert np.abs(np.abs(np.einsum("ij,ij->j", Vl.conj(), V)) - 1.0).max() <= 1e3 * EPS / gap
+
+
+def test_clustered_spectrum_goes_to_the_host_solver(monkeypatch):
+    """Repeated eigenvalues: the device vectors would not be orthogonal inside a cluster; device_eigh must notice (gap test) and
+    take dstemr -- and the decomposition must be as good as ever."""
+    from adaptive_matrix_solver_amd.engine import DeviceEngine
+    n = 300
+    rng = np.random.default_rng(5)
+    Q = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))[0]
+    lam = np.concatenate([np.full(40, 1.0), np.full(3, -2.0), np.linspace(2.0, 5.0, n - 43)])
+    A = (Q * lam[None, :]) @ Q.conj().T
+    A = (A + A.conj().T) / 2
+    eng = DeviceEngine(0, eigh_mode="device")
+    try:
+        w = eng.device_eigh(A)
+        assert eng.tridiag_solver == "host" and eng.tridiag_diag[0] < 1e-7
+        V = eng.ctx.get_eigvecs()
+        assert np.abs(np.sort(w) - np.sort(lam)).max() <= 1e-12
+        assert np.abs(A @ V - V * w[None, :]).max() <= 1e-12 and np.abs(V.conj().T @ V - np.eye(n)).max() <= 1e-12
+        # a well separated spectrum on the same engine: the device solver is used; MAUS_EIGH_TRIDIAG=host switches it off
+        B = scenarios.hermitian(n, 77)
+        wb = eng.device_eigh(B)
+        assert eng.tridiag_solver == "device"
+        assert np.abs(wb - sla.eigh(B, eigvals_only=True)).max() <= 1e-13
+        monkeypatch.setenv("MAUS_EIGH_TRIDIAG", "host")
+        wh = eng.device_eigh(scenarios.hermitian(n, 78))
+        assert eng.tridiag_solver == "host" and np.isfinite(wh).all()
+    finally:
+        eng.ctx.close()
+
+
+@pytest.mark.parametrize("scale", [1e-140, 1e120])
+def test_tridiagonal_solver_is_scale_free(ctx, scale):
+    n = 200
+    A = scenarios.hermitian(n, 91) * scale
+    ctx.set_matrix(A)
+    d, e = ctx.herm_tridiag()
+    w, (gap, resid, tnorm) = ctx.herm_tridiag_eig(d, e)
+    wl = sla.eigh(A, eigvals_only=True)
+    assert np.abs(w - wl).max() <= 40 * n * EPS * np.abs(wl).max()
+    assert gap > 1e-6 and resid < 1e-13
+    ctx.herm_backtransform(None)
+    V = ctx.get_eigvecs()
+    assert np.abs(A @ V - V * w[None, :]).max() <= 60 * n * EPS * np.abs(wl).max()
+
+
+def test_hermitian_eigenproblem_takes_its_condition_number_from_the_device_decomposition(monkeypatch):
+    """With the decomposition on the device the start-up diagnostics skip the LU-based estimator: the eigenvalues the shortcut
+    needs anyway give the exact 2-norm condition number (sigma_i = |lambda_i|), and the first loop body reuses the decomposition."""
+    import random
+    from adaptive_matrix_solver_amd import engine as eng_mod
+    from adaptive_matrix_solver_amd.solver import MAUS_Solver, ProblemType, SolutionCandidate
+    n = 1100                                                     # above MAUS_Solver's cond_exact_max
+    A = scenarios.hermitian(n, 31)
+    exact = np.linalg.cond(A)
+
+    def no_estimator(*a, **k):
+        raise AssertionError("the LU-based condition estimator ran")
+    monkeypatch.setattr(eng_mod, "estimate_condition_number", no_estimator)
+    calls = {"eigh": 0}
+    real = eng_mod.DeviceEngine.device_eigh
+    monkeypatch.setattr(eng_mod.DeviceEngine, "device_eigh", lambda self, M: (calls.__setitem__("eigh", calls["eigh"] + 1), real(self, M))[1])
+    np.random.seed(5); random.seed(5); SolutionCandidate._candidate_id_counter = 0
+    s = MAUS_Solver(A, ProblemType.EIGENVALUE, initial_num_candidates=10, quiet=True, eigh_mode="device")
+    try:
+        assert s.diag_info.get("condition_number_from_eigh") is True and not s.diag_info["condition_number_is_estimate"]
+        assert abs(s.cond_number - exact) <= 1e-9 * exact
+        assert s.engine.tridiag_solver == "device"
+        s.loop_body(1)
+        assert calls["eigh"] == 1
+        S = SolutionCandidate.State
+        assert all(c.state in (S.CONVERGED, S.RETIRED) for c in s.candidates if c.id < 10)
+    finally:
+        s.engine.ctx.close()
