@@ -1,6 +1,6 @@
-// Hermitian eigendecomposition on the device, the GEMM- and bandwidth-shaped parts of it (gfx950).
+// Hermitian eigendecomposition on the device (gfx950).
 //
-// Replaces the reduction and back-transformation inside the reference's once-per-candidate
+// Replaces the reference's once-per-candidate
 //     eigvals_h, eigvecs_h = scipy.linalg.eigh(A)                                  AMS:161
 // (LAPACK zheevr: zhetrd -> dstemr -> zunmtr; one decomposition per matrix here), which at n = 8192 costs 73 s
 // on the GPU box's host against 7 ms per loop body on the device:
@@ -8,8 +8,10 @@
 //                               64 columns + a rank-128 update of the trailing matrix per panel (one zgemm: [V W][W V]^H).
 //                               Half of the 16/3 n^3 flops are Hermitian matrix-vector products with the trailing matrix --
 //                               HBM-bound, 16/3 n^3 bytes with full storage -- the other half the MFMA zgemm.
-//   2. (host)                   the real symmetric tridiagonal eigenproblem, O(n^2): scipy.linalg.eigh_tridiagonal
-//                               (LAPACK dstemr, the same kernel zheevr uses) -- engine.py
+//   2. maus_herm_tridiag_eig    the real symmetric tridiagonal eigenproblem, O(n^2) per sweep: bisection on the Sturm count and
+//                               eigenvectors from the twisted factorisation, one thread per eigenpair; the caller
+//                               (engine.device_eigh) falls back to scipy.linalg.eigh_tridiagonal (LAPACK dstemr, the kernel
+//                               zheevr uses) for clustered spectra
 //   3. maus_herm_backtransform  V = Q Z, zunmtr semantics: blocks of 64 reflectors as I - V T V^H (zlarft), three zgemm
 //                               calls per block.
 // Phase convention: the reflectors are LAPACK's (zlarfg: beta real, v(1) = 1; H(i) acts on rows i+1..n-1), so Q e_1 = e_1
