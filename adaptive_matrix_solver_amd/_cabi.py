@@ -18,7 +18,7 @@ SYMBOLS = [
     "maus_ctx_create", "maus_ctx_destroy", "maus_last_error", "maus_device_info", "maus_abi_version",
     "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get", "maus_pop_copy", "maus_pop_device_ptr", "maus_hist_append", "maus_hist_get", "maus_hist_clear", "maus_hist_generation",
     "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_lu_reserve", "maus_lu_workspace_allocs", "maus_set_shared_device", "maus_lu_mw_aborts", "maus_relax_normalise", "maus_residual",
-    "maus_svd_power_step", "maus_svd_power_propose", "maus_svd_commit", "maus_set_eigvecs", "maus_herm_match", "maus_herm_tridiag", "maus_herm_tridiag_eig", "maus_herm_backtransform", "maus_get_eigvecs", "maus_gmres", "maus_gmres_pert", "maus_jacobi_check",
+    "maus_svd_power_step", "maus_svd_power_propose", "maus_svd_commit", "maus_set_eigvecs", "maus_herm_match", "maus_herm_tridiag", "maus_herm_tridiag_eig", "maus_herm_tridiag_eigvals", "maus_herm_backtransform", "maus_get_eigvecs", "maus_gmres", "maus_gmres_pert", "maus_jacobi_check",
     "maus_profile_union_ms", "maus_gram", "maus_zgemm_host", "maus_zgemm_bench", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
     "maus_profile_enable", "maus_profile_read", "maus_sync", "maus_mt19937_jump",
     "maus_device_count", "maus_comm_unique_id", "maus_comm_init", "maus_comm_destroy", "maus_comm_info",
@@ -94,6 +94,7 @@ def load_library():
         "maus_herm_tridiag": ([vp, vp, vp], C.c_int),
         "maus_herm_backtransform": ([vp, vp, C.c_int], C.c_int),
         "maus_herm_tridiag_eig": ([vp, vp, vp, C.c_int, vp, vp], C.c_int),
+        "maus_herm_tridiag_eigvals": ([vp, vp, vp, C.c_int, vp], C.c_int),
         "maus_get_eigvecs": ([vp, vp, C.c_int], C.c_int),
         "maus_gmres": ([vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_int, C.c_int, vp, vp, vp], C.c_int),
         "maus_gmres_pert": ([vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, C.c_double, C.c_int, C.c_int, vp, vp, vp, vp], C.c_int),
@@ -375,24 +376,35 @@ class Context:
         self._ck(self.lib.maus_herm_tridiag(self.h, _ptr(d), _ptr(e)), "maus_herm_tridiag")
         return d, e[: n - 1]
 
+    @staticmethod
+    def _scaled_tridiagonal(d, e):
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        e = np.ascontiguousarray(e, dtype=np.float64)
+        n = d.shape[0]
+        if e.shape[0] != max(n - 1, 0):
+            raise ValueError("tridiagonal matrix: e must have n - 1 entries")
+        t = max(float(np.max(np.abs(d))) if n else 0.0, float(np.max(np.abs(e))) if n > 1 else 0.0)
+        if not np.isfinite(t):
+            raise ValueError("tridiagonal matrix is not finite")
+        s = 2.0 ** int(np.floor(np.log2(t))) if t > 0.0 else 1.0           # a power of two: the scaling is exact
+        return n, d / s, np.ascontiguousarray(e / s if n > 1 else np.zeros(1)), s
+
+    def herm_tridiag_eigvals(self, d, e):
+        """Eigenvalues (ascending) of the real symmetric tridiagonal T = (d, e) by bisection on the device."""
+        n, ds, es, s = self._scaled_tridiagonal(d, e)
+        w = np.empty(n, dtype=np.float64)
+        self._ck(self.lib.maus_herm_tridiag_eigvals(self.h, _ptr(ds), _ptr(es), n, _ptr(w)), "maus_herm_tridiag_eigvals")
+        return w * s
+
     def herm_tridiag_eig(self, d, e):
         """Eigenvalues (ascending) of the real symmetric tridiagonal T = (d, e) by bisection on the device, its eigenvectors
         (twisted factorisation, no reorthogonalisation) left there for herm_backtransform(None).  Returns (w, diag) with diag =
         (smallest gap / ||T||, largest residual component / ||T||, ||T||): see engine.device_eigh for the acceptance rule.
         T is scaled by a power of two to ||T|| ~ 1 first (exact), so the squares of the off-diagonal stay in range."""
-        d = np.ascontiguousarray(d, dtype=np.float64)
-        e = np.ascontiguousarray(e, dtype=np.float64)
-        n = d.shape[0]
-        if e.shape[0] != max(n - 1, 0):
-            raise ValueError("herm_tridiag_eig: e must have n - 1 entries")
-        t = max(float(np.max(np.abs(d))) if n else 0.0, float(np.max(np.abs(e))) if n > 1 else 0.0)
-        if not np.isfinite(t):
-            raise ValueError("herm_tridiag_eig: T is not finite")
-        s = 2.0 ** int(np.floor(np.log2(t))) if t > 0.0 else 1.0
-        ds, es = d / s, (e / s if n > 1 else np.zeros(1))
+        n, ds, es, s = self._scaled_tridiagonal(d, e)
         w = np.empty(n, dtype=np.float64)
         diag = np.empty(3, dtype=np.float64)
-        self._ck(self.lib.maus_herm_tridiag_eig(self.h, _ptr(ds), _ptr(np.ascontiguousarray(es)), n, _ptr(w), _ptr(diag)), "maus_herm_tridiag_eig")
+        self._ck(self.lib.maus_herm_tridiag_eig(self.h, _ptr(ds), _ptr(es), n, _ptr(w), _ptr(diag)), "maus_herm_tridiag_eig")
         return w * s, (float(diag[0]), float(diag[1]), float(diag[2]) * s)
 
     def herm_backtransform(self, Z):

@@ -544,8 +544,8 @@ int maus_herm_backtransform(maus_ctx* c, const double* z_real, int col_major) {
 // real symmetric tridiagonal matrix (d, e).  diag_out[0] = smallest gap between neighbouring eigenvalues / ||T||,
 // diag_out[1] = largest residual component max_k |(T z - lambda z)_k| over all vectors / ||T||, diag_out[2] = ||T|| (the
 // Gershgorin radius); the caller decides from them whether to keep the result (see the kernels above).
-int maus_herm_tridiag_eig(maus_ctx* c, const double* d_host, const double* e_host, int n, double* w_out, double* diag_out) {
-    if (!d_host || (!e_host && n > 1) || !w_out || !diag_out || n < 1) FAIL(c, "maus_herm_tridiag_eig: bad arguments");
+static int tri_solve(maus_ctx* c, const double* d_host, const double* e_host, int n, double* w_out, double* diag_out, bool vectors) {
+    if (!d_host || (!e_host && n > 1) || !w_out || (vectors && !diag_out) || n < 1) FAIL(c, "maus_herm_tridiag_eig: bad arguments");
     HermClock clk;
     if (c->hz) { (void)hipFree(c->hz); c->hz = nullptr; c->hzn = 0; }
     // Gershgorin interval and the scale of the problem (host: 2 n numbers)
@@ -569,7 +569,7 @@ int maus_herm_tridiag_eig(maus_ctx* c, const double* d_host, const double* e_hos
         FAIL(c, "maus_herm_tridiag_eig: out of device memory"); } } while (0)
     TRI_ALLOC(dd, sizeof(double) * n); TRI_ALLOC(de, sizeof(double) * n); TRI_ALLOC(de2, sizeof(double) * n);
     TRI_ALLOC(dw, sizeof(double) * n); TRI_ALLOC(dn, sizeof(double) * n); TRI_ALLOC(dr, sizeof(double) * n);
-    TRI_ALLOC(Z, sizeof(double) * nn); TRI_ALLOC(B, sizeof(double) * nn);
+    if (vectors) { TRI_ALLOC(Z, sizeof(double) * nn); TRI_ALLOC(B, sizeof(double) * nn); }
 #undef TRI_ALLOC
     hipStream_t st = c->st;
     std::vector<double> ez(n, 0.0);
@@ -579,6 +579,11 @@ int maus_herm_tridiag_eig(maus_ctx* c, const double* d_host, const double* e_hos
     const dim3 g1((n + 255) / 256), b1(256);
     hipLaunchKernelGGL(tri_bisect_kernel, g1, b1, 0, st, dd, de2, n, gl, gu, pivmin, dw);
     if (clk.on) { (void)hipStreamSynchronize(st); clk.lap("tridiag eig: bisection"); }
+    if (!vectors) {
+        const int rc = maus_stage_d2h(c, w_out, dw, sizeof(double) * n, st);
+        cleanup();
+        return rc;
+    }
     hipLaunchKernelGGL(tri_twisted_kernel, g1, b1, 0, st, dd, de, n, dw, eps * std::max(tnorm, safmin / eps), Z, B, dn);
     hipLaunchKernelGGL(tri_scale_kernel, dim3((n + 255) / 256, n), b1, 0, st, Z, n, dn);
     hipLaunchKernelGGL(tri_resid_kernel, g1, b1, 0, st, dd, de, n, dw, Z, dr);
@@ -603,4 +608,14 @@ int maus_herm_tridiag_eig(maus_ctx* c, const double* d_host, const double* e_hos
     c->hz = Z; c->hzn = n; Z = nullptr;                              // kept for the back-transformation
     cleanup();
     return 0;
+}
+
+int maus_herm_tridiag_eig(maus_ctx* c, const double* d, const double* e, int n, double* w_out, double* diag_out) {
+    return tri_solve(c, d, e, n, w_out, diag_out, true);
+}
+
+// the eigenvalues alone (ascending): the bisection without the n x n work arrays -- singular values through the Hermitian
+// embedding, the reporting prologue's spectra
+int maus_herm_tridiag_eigvals(maus_ctx* c, const double* d, const double* e, int n, double* w_out) {
+    return tri_solve(c, d, e, n, w_out, nullptr, false);
 }

@@ -196,7 +196,7 @@ def estimate_condition_number(A, device=0, max_iter=25, rtol=1e-2):
 def singular_values_device(A, device=0):
     """All singular values of a dense matrix, descending, as the non-negative eigenvalues of the Hermitian embedding
     [[0, A], [A^H, 0]] (+-sigma_i and |rows - cols| zeros): tridiagonalised on the device (csrc/herm.hip), eigenvalues of the
-    tridiagonal matrix by LAPACK dsterf on the host.  The same absolute accuracy eps ||A|| as LAPACK's bidiagonal SVD -- what
+    tridiagonal matrix by bisection there too (tridiagonal_eigenvalues).  The same absolute accuracy eps ||A|| as LAPACK's bidiagonal SVD -- what
     np.linalg.cond and scipy.linalg.svd(compute_uv=False) deliver -- at a fraction of their O(n^3) host time."""
     import scipy.linalg as sla
     A = np.asarray(A, dtype=np.complex128)
@@ -208,10 +208,23 @@ def singular_values_device(A, device=0):
     try:
         cH.set_matrix(Hm)
         d, e = cH.herm_tridiag()
+        w = tridiagonal_eigenvalues(cH, d, e)
     finally:
         cH.close()
-    w = sla.eigvalsh_tridiagonal(d, e) if d.shape[0] > 1 else d
     return np.maximum(np.sort(w)[::-1][: min(r, c)], 0.0)
+
+
+def tridiagonal_eigenvalues(ctx, d, e):
+    """Eigenvalues of the real symmetric tridiagonal (d, e), ascending: bisection on the device (csrc/herm.hip; within half an ulp
+    of ||T|| of LAPACK dstebz) or, on MAUS_EIGH_TRIDIAG=host / non-finite input / a context without the entry point, LAPACK
+    dsterf on the host."""
+    import scipy.linalg as sla
+    if d.shape[0] <= 1:
+        return d.copy()
+    if (os.environ.get("MAUS_EIGH_TRIDIAG", "auto") != "host" and hasattr(ctx, "herm_tridiag_eigvals")
+            and np.isfinite(d).all() and np.isfinite(e).all()):
+        return ctx.herm_tridiag_eigvals(d, e)
+    return np.sort(sla.eigvalsh_tridiagonal(d, e))
 
 
 class DeviceEngine:

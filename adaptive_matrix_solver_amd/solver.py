@@ -900,10 +900,11 @@ class MAUS_Solver:
                     raise ValueError("Non-square matrix for Eigenvalue.")
                 if self.problem_knowledge.get("is_hermitian", False) and self.engine.use_device_eigh(self.N_rows):
                     # Hermitian: the spectrum of the tridiagonal matrix the device reduces M to (csrc/herm.hip) instead of a
-                    # general QR iteration on the host -- eigenvalues only (dsterf), real, in eigvals()'s sorted order
+                    # general QR iteration on the host -- eigenvalues only (bisection on the device), real, in eigvals()'s sorted order
                     self.engine.bind_matrix(self.M)
                     d, e = self.engine.ctx.herm_tridiag()
-                    return np.sort(sla.eigvalsh_tridiagonal(d, e) if d.shape[0] > 1 else d).astype(np.complex128)
+                    from .engine import tridiagonal_eigenvalues
+                    return np.sort(tridiagonal_eigenvalues(self.engine.ctx, d, e)).astype(np.complex128)
                 vals = sla.eigvals(self.M)
                 vals.sort()
                 return vals

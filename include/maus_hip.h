@@ -213,6 +213,9 @@ int maus_herm_tridiag(maus_ctx* ctx, double* d_out, double* e_out);
 int maus_get_eigvecs(maus_ctx* ctx, double* v_c128_out, int n);
 int maus_herm_backtransform(maus_ctx* ctx, const double* z_real, int col_major);
 int maus_herm_tridiag_eig(maus_ctx* ctx, const double* d, const double* e, int n, double* w_out, double* diag_out);
+/* the eigenvalues of T alone (bisection only, no n x n work arrays): singular values through the Hermitian embedding, spectra of
+ * the reporting prologue (AMS:559 / 567) */
+int maus_herm_tridiag_eigvals(maus_ctx* ctx, const double* d, const double* e, int n, double* w_out);
 
 /* Gram block of candidate vectors for the distinctness / redundancy tests      AMS:432-437, 443-451, 509-520:
  * out[i*count + j] = vdot(x_i, x_j) = sum_k conj(x_i[k]) x_j[k] over the first `len` entries of rows `slots`

@@ -291,3 +291,20 @@ def test_hermitian_eigenproblem_takes_its_condition_number_from_the_device_decom
         assert all(c.state in (S.CONVERGED, S.RETIRED) for c in s.candidates if c.id < 10)
     finally:
         s.engine.ctx.close()
+
+
+def test_eigenvalues_only_entry_point(ctx):
+    """maus_herm_tridiag_eigvals: the bisection alone -- repeated eigenvalues (the +-sigma pairs and zeros of a Hermitian embedding)
+    are no obstacle when no vectors are asked for."""
+    rng = np.random.default_rng(8)
+    B = rng.standard_normal((90, 60)) + 1j * rng.standard_normal((90, 60))
+    Hm = np.zeros((150, 150), dtype=np.complex128)
+    Hm[:90, 90:] = B
+    Hm[90:, :90] = B.conj().T
+    ctx.set_matrix(Hm)
+    d, e = ctx.herm_tridiag()
+    w = ctx.herm_tridiag_eigvals(d, e)
+    ref = np.sort(np.concatenate([sla.svd(B, compute_uv=False), -sla.svd(B, compute_uv=False), np.zeros(30)]))
+    assert w.shape == (150,) and np.all(np.diff(w) >= 0) and np.abs(w - ref).max() <= 1e-13 * ref[-1] * 150
+    one = ctx.herm_tridiag_eigvals(np.array([3.5]), np.zeros(0))
+    assert one.tolist() == [3.5]
