@@ -86,11 +86,16 @@ def cpu_allowance() -> int:
         n = len(os.sched_getaffinity(0))
     except Exception:
         n = os.cpu_count() or 1
-    for path in ("/sys/fs/cgroup/cpu.max",):
-        try:
-            quota, period = open(path).read().split()[:2]
-            if quota != "max":
-                n = min(n, max(1, int(int(quota) / int(period))))
+    try:                                                         # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:                                                     # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
         except Exception:
             pass
     return max(1, n)
