@@ -2,14 +2,14 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03
 mkdir -p $O
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu > $O/final7_tests.txt 2>&1
-echo "pytest rc=$?" >> $O/final7_tests.txt
-tail -4 $O/final7_tests.txt
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > $O/final8_tests.txt 2>&1
+echo "pytest rc=$?" >> $O/final8_tests.txt
+tail -4 $O/final8_tests.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout -k 10 500 python bench.py > $O/final7_c1.json 2> $O/final7_c1.err && python tools/bench_summary.py $O/final7_c1.json
+timeout -k 10 500 python bench.py > $O/final8_c1.json 2> $O/final8_c1.err && python tools/bench_summary.py $O/final8_c1.json
 for c in c2 c3 c4 c5; do
-  timeout -k 10 400 python bench.py --config $c > $O/final7_$c.json 2> $O/final7_$c.err || tail -5 $O/final7_$c.err
-  python - $O/final7_$c.json <<'PY'
+  timeout -k 10 400 python bench.py --config $c > $O/final8_$c.json 2> $O/final8_$c.err || tail -5 $O/final8_$c.err
+  python - $O/final8_$c.json <<'PY'
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
