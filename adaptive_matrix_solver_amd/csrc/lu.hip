@@ -758,39 +758,155 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
 
 #endif  // MAUS_NBP == 16
 
-// U[j..j+TW, cols] = L11^-1 * H[perm[j..j+TW), cols]: the pivot rows are gathered through perm and their finished U
-// rows written to the logical-order array.
-template <int TW, int BS = 256>
-__global__ void __launch_bounds__(BS)
-trsm_ip_kernel(const c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long strideH, const int* __restrict__ perm_g,
-               int npad, int j, int c_lo, int c_hi)
+// =======================================================================================
+// Triangular solves of the block rows,  U[j : j+k, cols] = L11^-1 * H[perm[j : j+k), cols],  k <= 128, on the matrix pipe
+// (round 4).  Round 3 ran them as a recursion of 32-row substitution kernels (one thread per column) and K = 32 / 64 zgemm
+// updates in between: 6.5 passes over every block row for its levels below 128, 15 dependent launches per 256-row solve.
+// Now one kernel per solve of up to 128 rows reads the block row ONCE and writes it ONCE:
+//   * one wave owns a strip of 16 columns and keeps all k x 16 entries of it in registers, in the accumulator layout of
+//     v_mfma_f64_16x16x4 (component r of block bi = row 16 bi + 4 r + lane/16, column lane%16).  That layout IS the B-operand
+//     layout of the same instruction (k-step s takes rows 4 s + lane/16), so a finished block X_bj feeds the products of the
+//     blocks below it without leaving the registers;
+//   * block forward substitution over 16-row blocks:  X_bi = Dinv_bi (B_bi - sum_{bj<bi} L[bi][bj] X_bj), every 16 x 16 complex
+//     block product as 3 real MFMA products (3M, the zgemm's form and rounding order); the L blocks are A operands read
+//     straight from the factored panel columns through perm (L2-resident: every strip of a matrix reads the same blocks);
+//   * Dinv_bi = inverse of the unit lower triangular 16 x 16 diagonal block (LAPACK's own large-n zgetrf reaches its U12
+//     through ztrsm, which libraries implement with inverted diagonal blocks as well).  |l| <= 1 under partial pivoting.  Its
+//     strictly lower part is computed once per block by lu_diaginv_kernel and kept where nothing else lives: below the
+//     diagonal of the same block of the logical-order U array.
+// All B tiles of a strip are requested before the first product (32 loads per lane in flight).
+// =======================================================================================
+__global__ void __launch_bounds__(64)
+lu_diaginv_kernel(const c128* __restrict__ Hg, c128* __restrict__ Ug, long strideH, const int* __restrict__ perm_g, int npad, int j)
 {
-    __shared__ c128 sL[TW][TW + 1];
-    __shared__ int sp[TW];
-    const c128* H = Hg + (long)blockIdx.y * strideH;              // tile-major (luws.h); ld = 64 = row step inside a tile
-    c128* U = Ug + (long)blockIdx.y * strideH;
-    if (threadIdx.x < TW) sp[threadIdx.x] = perm_g[(long)blockIdx.y * npad + j + threadIdx.x];
-    __syncthreads();
-    // this thread's column first (registers), then the triangle (LDS): both gathers are in flight together -- issued behind
-    // the barrier that publishes the triangle, the column's loads waited out a second memory latency in every launch
-    const int col = c_lo + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = col < c_hi;
-    const long tc = lu_tile_off(npad, live ? col : c_lo);
-    c128 x[TW];
+    const int g = blockIdx.y, jb = j + 16 * blockIdx.x, lane = threadIdx.x;
+    __shared__ c128 sL[16][17];
+    const c128* H = Hg + (long)g * strideH + lu_tile_off(npad, jb);
+    c128* U = Ug + (long)g * strideH + lu_tile_off(npad, jb) + (long)jb * LU_TW;
+    const int* perm = perm_g + (long)g * npad + jb;
 #pragma unroll
-    for (int i = 0; i < TW; ++i) x[i] = H[tc + (long)sp[i] * ld];
-    for (int e = threadIdx.x; e < TW * TW; e += blockDim.x) {
-        int r = e / TW, c = e % TW;                                // (j is a multiple of 16 only: a 32-wide block may straddle two tiles)
-        sL[r][c] = H[lu_tile_off(npad, j + c) + (long)sp[r] * ld];
+    for (int e = lane; e < 256; e += 64) { const int r = e >> 4, c = e & 15; sL[r][c] = H[(long)perm[r] * LU_TW + c]; }
+    __syncthreads();
+    if (lane < 16) {
+        // column `lane` of the inverse: x_c = 1, x_i = -sum_{k<i} L[i][k] x_k below it (x_k = 0 above)
+        c128 x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            c128 s = cmake(i == lane ? 1.0 : 0.0, 0.0);
+            if (i > lane) {
+#pragma unroll
+                for (int k = 0; k < i; ++k) cfms(s, sL[i][k], x[k]);
+            }
+            x[i] = s;
+        }
+#pragma unroll
+        for (int i = 1; i < 16; ++i) if (i > lane) U[(long)i * LU_TW + lane] = x[i];
     }
-    __syncthreads();
-    if (!live) return;
+}
+
+template <int NB>
+__global__ void __launch_bounds__(256, 2)
+trsm_mfma_kernel(const c128* __restrict__ Hg, c128* __restrict__ Ug, long strideH, const int* __restrict__ perm_g,
+                 int npad, int j, int c_lo, int c_hi)
+{
+    const int g = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col0 = c_lo + (blockIdx.x * 4 + wave) * 16;                   // this wave's strip (never straddles a 64-column tile)
+    if (col0 >= c_hi) return;                                               // wave-uniform; the kernel has no barrier
+    const c128* H = Hg + (long)g * strideH;
+    c128* U = Ug + (long)g * strideH;
+    const int* perm = perm_g + (long)g * npad + j;
+    const int q = lane >> 4, i16 = lane & 15;
+    // addresses = wave-uniform 64-bit base + 32-bit lane offset (a physical row is at most 8192 * 1 KB into a tile): one VGPR per
+    // address instead of two keeps the 4 NB tile loads that are in flight together inside the register budget
+    const c128* Hs = H + lu_tile_off(npad, col0);                            // this strip's tile column, physical row 0
+    c128* Us = U + lu_tile_off(npad, col0) + (long)j * LU_TW;                // this strip's tile column, logical row j
+    // the row lists first, then every B tile of the strip: 4 NB loads per lane in flight before the first product
+    unsigned lrow[NB];
+    d4 xr[NB], xi[NB];
+    {
+        unsigned prow[NB][4];
 #pragma unroll
-    for (int i = 1; i < TW; ++i)
+        for (int bi = 0; bi < NB; ++bi) {
 #pragma unroll
-        for (int q = 0; q < i; ++q) cfms(x[i], sL[i][q], x[q]);
+            for (int r = 0; r < 4; ++r) prow[bi][r] = (unsigned)perm[16 * bi + 4 * r + q] * LU_TW + i16;
+            lrow[bi] = (unsigned)perm[16 * bi + i16] * LU_TW + q;
+        }
 #pragma unroll
-    for (int i = 0; i < TW; ++i) U[tc + (long)(j + i) * ld] = x[i];
+        for (int bi = 0; bi < NB; ++bi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const c128 v = Hs[prow[bi][r]];
+                xr[bi][r] = v.x; xi[bi][r] = v.y;
+            }
+        }
+    }
+    // A-operand fragments: lane holds block element [row i16][column 4 s + q], s = 0..3
+    auto load_l = [&](int bi, int bj, c128 (&f)[4]) {
+        const c128* p = H + lu_tile_off(npad, j + 16 * bj);                  // uniform
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f[s] = p[lrow[bi] + 4 * s];
+    };
+    const unsigned drow = (unsigned)i16 * LU_TW + q;
+    auto load_d = [&](int bi, c128 (&f)[4]) {          // strictly lower part from memory, unit diagonal, zeros above
+        const c128* p = U + lu_tile_off(npad, j + 16 * bi) + (long)(j + 16 * bi) * LU_TW;     // uniform
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 4 * s + q;
+            const c128 v = p[drow + 4 * s];
+            f[s] = cmake(k < i16 ? v.x : (k == i16 ? 1.0 : 0.0), k < i16 ? v.y : 0.0);
+        }
+    };
+    // One flat sequence of block products -- for bi = 0, 1, ..: L[bi][0], .., L[bi][bi-1], then Dinv_bi -- with the A fragments of
+    // the NEXT product requested before the current one runs, across the bi boundaries too, and the stores of a finished block
+    // issued behind that request: vmcnt retires in order, so a load requested after the stores would wait for them.
+    auto load_blk = [&](int bi, int bj, c128 (&f)[4]) { if (bj < bi) load_l(bi, bj, f); else load_d(bi, f); };
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    c128 cur[4];
+    load_d(0, cur);
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+        {
+            d4 s1 = zero, s2 = zero, s3 = zero;
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                c128 nx[4];
+                const bool last = (bj == bi);
+                const int nbi = last ? bi + 1 : bi, nbj = last ? 0 : bj + 1;
+                const bool have_next = nbi < NB;
+                if (have_next) load_blk(nbi, nbj, nx);
+                if (!last) {
+                    const d4 xs = xr[bj] + xi[bj];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s].x, xr[bj][s], s1, 0, 0, 0);
+                        s2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s].y, xi[bj][s], s2, 0, 0, 0);
+                        s3 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s].x + cur[s].y, xs[s], s3, 0, 0, 0);
+                    }
+                } else {
+                    // the zgemm's 3M epilogue (re = P1 - P2, im = (P3 - P1) - P2), subtracted from the B tile
+                    const d4 tr = (bi > 0) ? xr[bi] - (s1 - s2) : xr[bi];
+                    const d4 ti = (bi > 0) ? xi[bi] - ((s3 - s1) - s2) : xi[bi];
+                    const d4 ts = tr + ti;
+                    d4 p1 = zero, p2 = zero, p3 = zero;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s].x, tr[s], p1, 0, 0, 0);
+                        p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s].y, ti[s], p2, 0, 0, 0);
+                        p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s].x + cur[s].y, ts[s], p3, 0, 0, 0);
+                    }
+                    xr[bi] = p1 - p2;
+                    xi[bi] = (p3 - p1) - p2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Us[(unsigned)((16 * bi + 4 * r + q) * LU_TW + i16)] = cmake(xr[bi][r], xi[bi][r]);
+                }
+                if (have_next) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) cur[s] = nx[s];
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -892,26 +1008,24 @@ static void lu_gemm(const LuWs& w, int r0, int r1, int c0, int c1, int k0, int k
 
 static void lu_trsm(const LuWs& w, int j, int k, int c_lo, int c_hi) {
     if (c_hi <= c_lo) return;
-    // base: one thread per column holds the 16 or 32 rows in registers (32 saves the level of 16-row zgemm updates)
-    static const int tw32 = [] { const char* e = getenv("MAUS_TRSM32"); return e ? atoi(e) : 1; }();
-    if (k <= NBP || (tw32 && k == 32)) {
-        prof(w, KC_TRSM, 0);
-        dim3 grid((c_hi - c_lo + 255) / 256, w.G);
-        // small batches: one wave per workgroup, four times as many workgroups (a thread walks its 32 rows one after
-        // the other; with one 256-thread workgroup per CU or less nothing hides the latency of its loads)
-        const bool thin = (long)grid.x * w.G < 1024;
-        dim3 g64((c_hi - c_lo + 63) / 64, w.G);
-        if (k == 32 && NBP < 32) {
-            if (thin) hipLaunchKernelGGL((trsm_ip_kernel<32, 64>), g64, dim3(64), 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
-            else hipLaunchKernelGGL((trsm_ip_kernel<32>), grid, dim3(256), 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
-        } else {
-            if (thin) hipLaunchKernelGGL((trsm_ip_kernel<NBP, 64>), g64, dim3(64), 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
-            else hipLaunchKernelGGL((trsm_ip_kernel<NBP>), grid, dim3(256), 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, w.perm, w.npad, j, c_lo, c_hi);
+    // up to 128 rows: one launch of the register-resident MFMA solve (trsm_mfma_kernel); beyond that two halves with the
+    // zgemm update between them
+    if (k <= 128) {
+        if (w.dinv_upto < j + k) {          // inverses of the diagonal blocks factored since the last solve (panels finish left to right)
+            prof(w, KC_TRSM, 0);
+            hipLaunchKernelGGL(lu_diaginv_kernel, dim3((j + k - w.dinv_upto) / 16, w.G), dim3(64), 0, w.st, w.H, w.U, w.strideH, w.perm, w.npad, w.dinv_upto);
+            prof(w, KC_TRSM, 1, 0, 0);
+            w.dinv_upto = j + k;
         }
+        prof(w, KC_TRSM, 0);
+        dim3 grid(((c_hi - c_lo) / 16 + 3) / 4, w.G);
+#define TRSM_MFMA(NB) case NB: hipLaunchKernelGGL((trsm_mfma_kernel<NB>), grid, dim3(256), 0, w.st, w.H, w.U, w.strideH, w.perm, w.npad, j, c_lo, c_hi); break
+        switch (k / 16) { TRSM_MFMA(1); TRSM_MFMA(2); TRSM_MFMA(3); TRSM_MFMA(4); TRSM_MFMA(5); TRSM_MFMA(6); TRSM_MFMA(7); TRSM_MFMA(8); }
+#undef TRSM_MFMA
         prof(w, KC_TRSM, 1, 4.0 * k * k * (c_hi - c_lo) * w.G, 32.0 * k * (c_hi - c_lo) * w.G);
         return;
     }
-    int h = (k >= 2 * NBP) ? (k / (2 * NBP)) * NBP : NBP;
+    const int h = (k / 32) * 16;
     lu_trsm(w, j, h, c_lo, c_hi);
     lu_gemm(w, j + h, j + k, c_lo, c_hi, j, j + h);
     lu_trsm(w, j + h, k - h, c_lo, c_hi);
@@ -992,6 +1106,7 @@ size_t maus_lu_mw_sync_bytes() { return 64; }
 // Factor all G matrices in the workspace and carry the augmented column through (L y = P b).
 void maus_lu_factor(const LuWs& w, int nbo) {
     const int ncols = (int)w.ldh;                 // npad + 32
+    w.dinv_upto = 0;
     hipLaunchKernelGGL(init_perm_kernel, dim3((w.npad + 255) / 256, w.G), dim3(256), 0, w.st, w.perm, w.npad);
     for (int J = 0; J < w.npad; J += nbo) {
         int wd = (w.npad - J < nbo) ? (w.npad - J) : nbo;
