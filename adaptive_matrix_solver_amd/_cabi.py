@@ -19,7 +19,7 @@ SYMBOLS = [
     "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get", "maus_pop_copy", "maus_pop_device_ptr", "maus_hist_append", "maus_hist_get", "maus_hist_clear", "maus_hist_generation",
     "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_lu_reserve", "maus_lu_workspace_allocs", "maus_set_shared_device", "maus_lu_mw_aborts", "maus_relax_normalise", "maus_residual",
     "maus_svd_power_step", "maus_svd_power_propose", "maus_svd_commit", "maus_set_eigvecs", "maus_herm_match", "maus_herm_tridiag", "maus_herm_tridiag_eig", "maus_herm_tridiag_eigvals", "maus_herm_backtransform", "maus_get_eigvecs", "maus_gmres", "maus_gmres_pert", "maus_jacobi_check",
-    "maus_profile_union_ms", "maus_gram", "maus_zgemm_host", "maus_zgemm_bench", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
+    "maus_profile_union_ms", "maus_gram", "maus_zgemm_host", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
     "maus_profile_enable", "maus_profile_read", "maus_sync", "maus_mt19937_jump",
     "maus_device_count", "maus_comm_unique_id", "maus_comm_init", "maus_comm_destroy", "maus_comm_info",
     "maus_comm_allgather_records", "maus_comm_allgather_rows", "maus_comm_bcast", "maus_comm_bcast_eigvecs", "maus_comm_stats",
@@ -103,7 +103,6 @@ def load_library():
         "maus_gram": ([vp, C.c_int, vp, C.c_int, C.c_int, vp], C.c_int),
         "maus_zgemm_host": ([vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int], C.c_int),
         "maus_lu_solve_host": ([vp, C.c_int, C.c_int, vp, vp, vp, vp, vp], C.c_int),
-        "maus_zgemm_bench": ([vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)], C.c_int),
         "maus_timer_start": ([vp], C.c_int),
         "maus_timer_stop": ([vp, C.POINTER(C.c_float)], C.c_int),
         "maus_profile_enable": ([vp, C.c_int], C.c_int),
@@ -532,11 +531,6 @@ class Context:
         self._ck(self.lib.maus_zgemm_host(self.h, M, N, K, _ptr(A), _ptr(B), _ptr(Cm), int(b_layout), int(conj_a),
                                           int(conj_b), float(alpha), int(beta)), "maus_zgemm_host")
         return Cm
-
-    def zgemm_bench(self, M, N, K, ld, batch, iters=5):
-        ms = C.c_float()
-        self._ck(self.lib.maus_zgemm_bench(self.h, M, N, K, ld, batch, iters, C.byref(ms)), "maus_zgemm_bench")
-        return float(ms.value)
 
     def lu_solve(self, A, b, want_ipiv=False):
         A = _c128(A)

@@ -582,17 +582,16 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     if (c->flags) { (void)hipFree(c->flags); c->flags = nullptr; }
     c->Hg = 0; c->Hbytes = 0; c->ws_at_limit = false;
     const int G_asked = G;
-    // The big allocation can fail although hipMemGetInfo just reported the room (memory of a process that has only just
-    // exited is handed back with a delay: seen with back-to-back bench runs on one box).  Wait a little, then make do
-    // with less -- batches beyond the workspace run in chunks -- rather than fail the step.
+    // The big allocation can fail although hipMemGetInfo just reported the room (the 80 % rule above is a guess at what
+    // fragmentation and other contexts leave).  Then make do with less -- batches beyond the workspace run in chunks -- rather
+    // than fail the step.  (Round 2 also slept and retried here, on the theory that memory of a process that has just exited
+    // comes back late; that was never shown and is gone.)
     {
         const int floor_g = std::min(G, std::max(32, round_up(std::min(want, 64), 32)));
-        int tries = 0;
         while (hipMalloc((void**)&c->H, per * G) != hipSuccess) {
             (void)hipGetLastError();
             c->H = nullptr;
-            if (++tries <= 4) { usleep(250000); }
-            else if (G > floor_g) { G = std::max(floor_g, std::min(G - 32, (G * 3 / 4) / 32 * 32)); }
+            if (G > floor_g) G = std::max(floor_g, std::min(G - 32, (G * 3 / 4) / 32 * 32));
             else FAIL(c, "LU workspace: hipMalloc failed even for the smallest batch (out of device memory)");
         }
     }
@@ -618,7 +617,7 @@ static LuWs make_ws(maus_ctx* c, int n, int G) {
     return w;
 }
 
-// Sub-batches on their own streams, each at least MAUS_LU_MIN_SUB (64) matrices (see maus_shifted_lu_solve): MAUS_LU_STREAMS if set;
+// Sub-batches on their own streams, each at least 64 matrices (see maus_shifted_lu_solve): MAUS_LU_STREAMS if set;
 // otherwise one stream, except two for more matrices than CUs at n <= 1024 -- there the register-resident panel, the triangular
 // solves and the back-substitution run one workgroup per matrix on a whole CU, so 271 matrices mean a second, nearly empty round
 // of every such launch (n = 1024: 256 -> 271 matrices cost 27.8 -> 32.2 ms), and two halves of <= 256 side by side do not
@@ -636,12 +635,11 @@ static int ensure_lu_streams(maus_ctx* c, int n) {
     while ((int)c->lu_st.size() < n) {
         hipStream_t s; hipEvent_t e;
         // descending priorities keep the sub-batches out of phase: while the first one is in an MFMA-bound trailing
-        // update the next one gets the left-over issue slots for its bandwidth-bound panel / swap work, and vice versa
+        // update the next one gets the left-over issue slots for its bandwidth-bound panel work, and vice versa
         int plo = 0, phi = 0;
         (void)hipDeviceGetStreamPriorityRange(&plo, &phi);          // plo = least, phi = greatest (numerically lower)
-        const char* pe = getenv("MAUS_LU_PRIO");
         const int idx = (int)c->lu_st.size();
-        int prio = (pe && atoi(pe) == 0) ? 0 : std::max(phi, std::min(plo, phi + idx));
+        const int prio = std::max(phi, std::min(plo, phi + idx));
         HIPCHK(c, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
         HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(c, hipEventRecord(e, s));                            // the hardware queue behind a stream is set up at its first
@@ -784,14 +782,14 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
             if (maus_stage_h2d(c, c->Upert, (const double*)pert_data + 2 * (size_t)n * n * off, ub, c->st)) return -1;
             dU = c->Upert;
         }
-        // One stream at n = 4096 (lu_stream_count).  MAUS_LU_STREAMS=<n> splits a batch into min(n, G / MAUS_LU_MIN_SUB)
+        // One stream at n = 4096 (lu_stream_count).  MAUS_LU_STREAMS=<n> splits a batch into min(n, G / 64)
         // sub-batches on their own streams so that the bandwidth- and latency-bound phases of one (panel, triangular solves,
         // H build) run beside the MFMA-bound trailing updates of the others.  That paid 0-2 % while those phases ran at
         // 2.4-4 TB/s (round 2, where a run-time tuner picked the count per batch-size class); with the tile-major workspace
         // they run at ~5 TB/s, the zgemm beside them loses more than they gain, and whole driver-shaped runs give 352 / 338
         // candidate-steps/s with 1 / 2 streams (profiles/r03_streams_fixed.txt) -- the tuner, which picked three from one
         // noisy sample per count, is gone.  Results do not depend on the split (tests/test_gpu_bench_path.py: bit-equal).
-        static const int min_sub = [] { const char* e = getenv("MAUS_LU_MIN_SUB"); return e ? std::max(1, atoi(e)) : 64; }();
+        constexpr int min_sub = 64;                 // smallest sub-batch that gets a stream of its own
         const int S = std::max(1, std::min(nst, G / min_sub));
         // One more pass without the multi-workgroup panel if a rendezvous of it timed out (info = INT_MIN): its premise --
         // all workgroups of a matrix resident at once -- does not hold on a device that somebody else is using too.  The
@@ -1080,38 +1078,6 @@ int maus_zgemm_host(maus_ctx* c, int M, int N, int K, const double* A, const dou
     { ProfScope ps(c, KC_GEMM, 8.0 * M * N * K, 16.0 * (ea + eb + 2.0 * ec));
       maus_zgemm_launch_idx(c->st, M, N, K, dA, K, 0, dB, b_layout ? K : N, 0, dC, N, 0, alpha, beta, 1, b_layout, conj_a != 0, conj_b != 0, nullptr, nullptr); }
     if (maus_stage_d2h(c, C, dC, sizeof(c128) * ec, c->st)) return -1;
-    HIPCHK(c, hipGetLastError());
-    return 0;
-}
-
-__global__ void fill_rand_kernel(double* p, size_t n, unsigned seed) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += st) { unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; p[i] = (double)(x & 0xffffff) / 16777216.0 - 0.5; }
-}
-
-int maus_zgemm_bench(maus_ctx* c, int M, int N, int K, int ld, int batch, int iters, float* ms_out) {
-    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || iters <= 0 || ld < std::max(N, K) + K) FAIL(c, "maus_zgemm_bench: bad sizes");
-    // one array per matrix with rows = max(M, K) + K, laid out like the LU workspace: A = rows K.., cols 0..K ;
-    // B = rows 0..K, cols K.. ; C = rows K.., cols K..
-    const long rows = (long)M + K;
-    const size_t per = (size_t)rows * ld;
-    if (ensure_scratch(c, sizeof(c128) * per * batch)) return -1;
-    c128* base = (c128*)c->scratch;
-    if (getenv("MAUS_BENCH_ZERO")) { HIPCHK(c, hipMemsetAsync(base, 0, sizeof(c128) * per * batch, c->st)); }   // DVFS check
-    else hipLaunchKernelGGL(fill_rand_kernel, dim3(2048), dim3(256), 0, c->st, (double*)base, per * batch * 2, 12345u);
-    const long sAB = getenv("MAUS_BENCH_SHARED_AB") ? 0 : (long)per;     // measurement aid: every matrix reads the same A and B
-    auto launch = [&]() {
-        maus_zgemm_launch_idx(c->st, M, N, K, base + (size_t)K * ld, ld, sAB, base + K, ld, sAB,
-                              base + (size_t)K * ld + K, ld, (long)per, -1.0, 1, batch, 0, false, false, nullptr, nullptr);
-    };
-    launch();
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    HIPCHK(c, hipEventRecord(c->t0, c->st));
-    for (int i = 0; i < iters; ++i) launch();
-    HIPCHK(c, hipEventRecord(c->t1, c->st));
-    HIPCHK(c, hipEventSynchronize(c->t1));
-    float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, c->t0, c->t1));
-    *ms_out = ms / iters;
     HIPCHK(c, hipGetLastError());
     return 0;
 }

@@ -21,14 +21,19 @@
 // the same T perturbed in the last bit, tests/test_gpu_herm_eigh.py).  Nothing downstream sees it: the distinctness and
 // redundancy tests take |<v, s>| (AMS:436, 515), a candidate converged through the shortcut is not stepped again.
 //
-// Per column i of a panel (m' = n-i-1), six small launches, nothing returns to the host until the end:
-//   colupd   a(i:n,i) -= V(i:n,0:j) conj(W(i,0:j)) + W(i:n,0:j) conj(V(i,0:j))            (row-parallel; partial |.|^2)
-//   larfg    xnorm from the partials in fixed order, beta / tau / scale, v -> panel column j and the reflector store
-//   hemv     w0 = A22 v   (A22 = the trailing matrix as the previous panels left it: this panel's reflectors come in below)
-//   dots     t1 = W(:,0:j)^H v, t2 = V(:,0:j)^H v
-//   wfin1    w = tau (w0 - V t1 - W t2); partial w^H v
-//   wfin2    w += (-1/2 tau w^H v) v  -> panel column j of W
-// All reductions run in a fixed order (no atomics), so a decomposition is reproducible bit for bit.
+// Per column i of a panel (m' = n-i-1) three launches (round 4; six in round 3 -- 49 000 launches of 4-9 us at n = 8192 were
+// the second largest cost of the reduction and more dispatches in flight than a counter-collecting profiler could take):
+//   col1   a(i:n,i) -= V(i:n,0:j) conj(W(i,0:j)) + W(i:n,0:j) conj(V(i,0:j))            (row-parallel; partial |.|^2; d(i))
+//   col2   every workgroup repeats zlarfg's scalar part from the partials in fixed order (beta / tau / scale; workgroup 0 keeps
+//          e(i), tau(i)) and forms v = scale * a on the fly; then, by workgroup index,
+//            hemv:  w0 = A22 v for four rows, v -> panel column j and the reflector store, partial w0^H v
+//                   (A22 = the trailing matrix as the previous panels left it: this panel's reflectors come in below)
+//            dots:  t1 = W(:,0:j)^H v, t2 = V(:,0:j)^H v, one column each
+//   col3   u = w0 - V t1 - W t2,  w = tau u + alpha v  -> panel column j of W,  alpha = -1/2 tau (w^H v) with
+//          w^H v = conj(tau) (w0^H v - 2 Re sum_k conj(t1_k) t2_k)  from the partials and the dots: no second pass over w;
+//          rows <= i of a panel column are neither written nor read
+// All reductions run in a fixed order (no atomics), so a decomposition is reproducible bit for bit.  The host keeps at most two
+// panels of launches in flight.
 #include "ctx.h"
 #include <chrono>
 #include <cstdio>
@@ -54,140 +59,172 @@ __device__ __forceinline__ double block_sum_d(double v, double* sbuf) {
     return s;
 }
 
-// a(i:n, i) with the panel's earlier reflectors applied; col[r] for r in [i, n); part[block] = sum |a(r)|^2 over its rows >= i+2
-__global__ void __launch_bounds__(HT)
-herm_colupd_kernel(const c128* __restrict__ Aw, int n, int i, int j, const c128* __restrict__ PV, const c128* __restrict__ PW,
-                   c128* __restrict__ col, double* __restrict__ part)
+// a(i:n, i) with the panel's earlier reflectors applied; col[r] for r in [i, n); part[block] = sum |a(r)|^2 over its rows >= i+2.
+// 64 rows per workgroup, the 2 j terms of a row split over its four waves (partial sums combined in a fixed order): with a
+// whole row's terms in one thread the launch was 32 workgroups of 126 dependent loads each, 18 us per column at n = 8192.
+constexpr int HR = 64;         // rows per workgroup of col1 / col3
+__global__ void __launch_bounds__(256)
+herm_col1_kernel(const c128* __restrict__ Aw, int n, int i, int j, const c128* __restrict__ PV, const c128* __restrict__ PW,
+                 c128* __restrict__ col, double* __restrict__ part, double* __restrict__ d)
 {
     __shared__ c128 sw[HNB], sv[HNB];
-    __shared__ double sbuf[HT / 64];
-    const int tid = threadIdx.x;
+    __shared__ c128 sp[4][HR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < j) { sw[tid] = cconj(PW[(long)tid * n + i]); sv[tid] = cconj(PV[(long)tid * n + i]); }
     __syncthreads();
-    const int r = i + blockIdx.x * HT + tid;
-    double ss = 0.0;
+    const int r = i + blockIdx.x * HR + lane;
+    const int kc = (j + 3) / 4, k0 = wave * kc, k1 = min(j, k0 + kc);
+    c128 p = cmake(0.0, 0.0);
     if (r < n) {
-        c128 a = Aw[(long)r * n + i];
-        for (int k = 0; k < j; ++k) { cfms(a, PV[(long)k * n + r], sw[k]); cfms(a, PW[(long)k * n + r], sv[k]); }
-        col[r] = a;
-        if (r >= i + 2) ss = fma(a.x, a.x, a.y * a.y);
+        // four columns of V and of W requested together: with one pair per iteration the loop waited out a memory latency per term
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            c128 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = PV[(long)(k + u) * n + r]; b[u] = PW[(long)(k + u) * n + r]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { cfma(p, a[u], sw[k + u]); cfma(p, b[u], sv[k + u]); }
+        }
+        for (; k < k1; ++k) { cfma(p, PV[(long)k * n + r], sw[k]); cfma(p, PW[(long)k * n + r], sv[k]); }
     }
-    ss = block_sum_d(ss, sbuf);
-    if (tid == 0) part[blockIdx.x] = ss;
+    sp[wave][lane] = p;
+    __syncthreads();
+    if (wave == 0) {
+        double ss = 0.0;
+        if (r < n) {
+            const c128 q = cadd(cadd(sp[0][lane], sp[1][lane]), cadd(sp[2][lane], sp[3][lane]));
+            const c128 a = csub(Aw[(long)r * n + i], q);
+            col[r] = a;
+            if (r == i) d[i] = a.x;
+            if (r >= i + 2) ss = fma(a.x, a.x, a.y * a.y);
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) part[blockIdx.x] = ss;
+    }
 }
 
-// zlarfg on (alpha = col[i+1], x = col[i+2:n]); d[i], e[i], tau[i]; v -> PV[j] and VQ[i] (zeros above, 1 at i+1)
-__global__ void __launch_bounds__(1024)
-herm_larfg_kernel(const c128* __restrict__ col, int n, int i, int j, const double* __restrict__ part, int nparts,
-                  c128* __restrict__ PV, c128* __restrict__ VQ, c128* __restrict__ tau, double* __restrict__ d, double* __restrict__ e)
+// zlarfg's scalars for (alpha = col[i+1], x = col[i+2:n]); ss = sum |x|^2
+struct Larfg { c128 tau, scal; double beta; };
+__device__ __forceinline__ Larfg herm_larfg_scalars(const c128* __restrict__ col, int i, double ss)
+{
+    const double xnorm = sqrt(ss);
+    const c128 alpha = col[i + 1];
+    Larfg L;
+    L.tau = cmake(0.0, 0.0); L.scal = cmake(0.0, 0.0); L.beta = alpha.x;
+    if (!(xnorm == 0.0 && alpha.y == 0.0)) {
+        const double w = fmax(fmax(fabs(alpha.x), fabs(alpha.y)), xnorm);        // dlapy3
+        const double ax = alpha.x / w, ay = alpha.y / w, xn = xnorm / w;
+        const double nrm = w * sqrt(ax * ax + ay * ay + xn * xn);
+        L.beta = -copysign(nrm, alpha.x);
+        L.tau = cmake((L.beta - alpha.x) / L.beta, -alpha.y / L.beta);
+        L.scal = crecip(cmake(alpha.x - L.beta, alpha.y));
+    }
+    return L;
+}
+
+// Workgroups [0, nh): w0[r] = sum_{c > i} Aw[r][c] v[c] for r > i, one wave per row, four rows per workgroup; v -> PV[j], VQ[i]
+// (zeros above, 1 at i+1); cpart[b] = sum over the workgroup's rows of conj(w0_r) v_r.
+// Workgroups [nh, nh + 2j): t[k] = W_k^H v (k < j), t[j + k] = V_k^H v over the rows > i.
+__global__ void __launch_bounds__(256)
+herm_col2_kernel(const c128* __restrict__ Aw, int n, int i, int j, int nh, const c128* __restrict__ col, const double* __restrict__ part,
+                 int nparts, c128* __restrict__ PV, const c128* __restrict__ PW, c128* __restrict__ VQ, c128* __restrict__ tau,
+                 double* __restrict__ e, c128* __restrict__ w0, c128* __restrict__ cpart, c128* __restrict__ t)
 {
     __shared__ c128 s_scal;
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        d[i] = col[i].x;
-        if (i + 1 < n) {
-            double ss = 0.0;
-            for (int q = 0; q < nparts; ++q) ss += part[q];
-            const double xnorm = sqrt(ss);
-            const c128 alpha = col[i + 1];
-            c128 t = cmake(0.0, 0.0), scal = cmake(0.0, 0.0);
-            double beta = alpha.x;
-            if (!(xnorm == 0.0 && alpha.y == 0.0)) {
-                const double w = fmax(fmax(fabs(alpha.x), fabs(alpha.y)), xnorm);        // dlapy3
-                const double ax = alpha.x / w, ay = alpha.y / w, xn = xnorm / w;
-                const double nrm = w * sqrt(ax * ax + ay * ay + xn * xn);
-                beta = -copysign(nrm, alpha.x);
-                t = cmake((beta - alpha.x) / beta, -alpha.y / beta);
-                scal = crecip(cmake(alpha.x - beta, alpha.y));
-            }
-            tau[i] = t; e[i] = beta; s_scal = scal;
+    __shared__ double sbuf[4];
+    __shared__ c128 s_dot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave == 0) {
+        // the |.|^2 partials of col1 in a fixed order: lane-strided, then the butterfly -- the same bits in every workgroup
+        double ss = 0.0;
+        for (int q = lane; q < nparts; q += 64) ss += part[q];
+        ss = wave_sum(ss);
+        if (lane == 0) {
+            const Larfg L = herm_larfg_scalars(col, i, ss);
+            s_scal = L.scal;
+            if (blockIdx.x == 0) { tau[i] = L.tau; e[i] = L.beta; }
         }
     }
     __syncthreads();
-    if (i + 1 >= n) return;
     const c128 scal = s_scal;
-    c128* pv = PV + (long)j * n;
-    c128* vq = VQ + (long)i * n;
-    for (int r = tid; r < n; r += blockDim.x) {
-        c128 v = cmake(0.0, 0.0);
-        if (r == i + 1) v = cmake(1.0, 0.0);
-        else if (r > i + 1) v = cmul(col[r], scal);
-        pv[r] = v; vq[r] = v;
-    }
-}
-
-// w0[r] = sum_{c > i} Aw[r][c] v[c] for r > i: one wave per row, four rows per workgroup
-__global__ void __launch_bounds__(256)
-herm_hemv_kernel(const c128* __restrict__ Aw, int n, int i, const c128* __restrict__ v, c128* __restrict__ w0)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = i + 1 + blockIdx.x * 4 + wave;
-    if (r >= n) return;
-    const c128* row = Aw + (long)r * n;
-    c128 s0 = cmake(0.0, 0.0), s1 = s0, s2 = s0, s3 = s0;
-    int c = i + 1 + lane;
-    for (; c + 192 < n; c += 256) {
-        cfma(s0, row[c], v[c]); cfma(s1, row[c + 64], v[c + 64]); cfma(s2, row[c + 128], v[c + 128]); cfma(s3, row[c + 192], v[c + 192]);
-    }
-    for (; c < n; c += 64) cfma(s0, row[c], v[c]);
-    const double sr = wave_sum((s0.x + s1.x) + (s2.x + s3.x)), si = wave_sum((s0.y + s1.y) + (s2.y + s3.y));
-    if (lane == 0) w0[r] = cmake(sr, si);
-}
-
-// blocks 0..j-1: t[k] = W_k^H v ; blocks j..2j-1: t[j + k] = V_k^H v   (rows > i)
-__global__ void __launch_bounds__(HT)
-herm_dots_kernel(const c128* __restrict__ PV, const c128* __restrict__ PW, int n, int i, int j, const c128* __restrict__ v, c128* __restrict__ t)
-{
-    __shared__ double sbuf[HT / 64];
+    auto vat = [&](int c) { return (c == i + 1) ? cmake(1.0, 0.0) : cmul(col[c], scal); };     // c > i
     const int b = blockIdx.x;
-    const c128* p = (b < j) ? PW + (long)b * n : PV + (long)(b - j) * n;
-    c128 s = cmake(0.0, 0.0);
-    for (int r = i + 1 + threadIdx.x; r < n; r += HT) cfma_conj(s, p[r], v[r]);
-    const double sr = block_sum_d(s.x, sbuf), si = block_sum_d(s.y, sbuf);
-    if (threadIdx.x == 0) t[b] = cmake(sr, si);
+    if (b < nh) {
+        const int r = i + 1 + b * 4 + wave;
+        c128 dot = cmake(0.0, 0.0);
+        if (r < n) {
+            const c128* row = Aw + (long)r * n;
+            c128 s0 = cmake(0.0, 0.0), s1 = s0, s2 = s0, s3 = s0;
+            int c = i + 1 + lane;
+            for (; c + 192 < n; c += 256) {
+                cfma(s0, row[c], vat(c)); cfma(s1, row[c + 64], vat(c + 64)); cfma(s2, row[c + 128], vat(c + 128)); cfma(s3, row[c + 192], vat(c + 192));
+            }
+            for (; c < n; c += 64) cfma(s0, row[c], vat(c));
+            const double sr = wave_sum((s0.x + s1.x) + (s2.x + s3.x)), si = wave_sum((s0.y + s1.y) + (s2.y + s3.y));
+            if (lane == 0) {
+                const c128 wr = cmake(sr, si), vr = vat(r);
+                w0[r] = wr;
+                PV[(long)j * n + r] = vr; VQ[(long)i * n + r] = vr;
+                cfma_conj(dot, wr, vr);
+            }
+        }
+        if (lane == 0) s_dot[wave] = dot;
+        __syncthreads();
+        if (tid == 0) cpart[b] = cadd(cadd(s_dot[0], s_dot[1]), cadd(s_dot[2], s_dot[3]));
+    } else {
+        const int k = b - nh;
+        const c128* p = (k < j) ? PW + (long)k * n : PV + (long)(k - j) * n;
+        c128 s = cmake(0.0, 0.0);
+        for (int r = i + 1 + tid; r < n; r += 256) cfma_conj(s, p[r], vat(r));
+        const double sr = block_sum_d(s.x, sbuf), si = block_sum_d(s.y, sbuf);
+        if (tid == 0) t[k] = cmake(sr, si);
+    }
 }
 
-// w = tau (w0 - V t2' - W t1'): LAPACK's order -- w -= V (W^H v), then w -= W (V^H v); partial sum_r conj(w_r) v_r
-__global__ void __launch_bounds__(HT)
-herm_wfin1_kernel(const c128* __restrict__ PV, const c128* __restrict__ PW, int n, int i, int j, const c128* __restrict__ v,
-                  const c128* __restrict__ w0, const c128* __restrict__ t, const c128* __restrict__ tau, c128* __restrict__ wbuf,
-                  c128* __restrict__ cpart)
+// u = w0 - V (W^H v) - W (V^H v), w = tau u + alpha v -> panel column j of W.  Rows and terms are laid out
+// as in col1.
+__global__ void __launch_bounds__(256)
+herm_col3_kernel(const c128* __restrict__ PV, c128* __restrict__ PW, int n, int i, int j, const c128* __restrict__ w0,
+                 const c128* __restrict__ t, const c128* __restrict__ tau, const c128* __restrict__ cpart, int nh)
 {
     __shared__ c128 st[2 * HNB];
-    __shared__ double sbuf[HT / 64];
-    const int tid = threadIdx.x;
+    __shared__ double sbuf[4];
+    __shared__ c128 s_alpha;
+    __shared__ c128 sp[4][HR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 2 * j) st[tid] = t[tid];
-    __syncthreads();
-    const int r = i + 1 + blockIdx.x * HT + tid;
-    c128 dot = cmake(0.0, 0.0);
+    // u^H v = w0^H v - 2 Re sum_k conj(t1_k) t2_k: the partials of col2 and, from thread k < j, its term of the correction
+    c128 ds = cmake(0.0, 0.0);
+    for (int q = tid; q < nh; q += 256) ds = cadd(ds, cpart[q]);
+    if (tid < j) { const c128 a = t[tid], b = t[j + tid]; ds.x -= 2.0 * (a.x * b.x + a.y * b.y); }
+    const double dr = block_sum_d(ds.x, sbuf), di = block_sum_d(ds.y, sbuf);       // (the barriers inside also publish st)
+    if (tid == 0) {
+        const c128 tq = tau[i];
+        const c128 whv = cmul(cconj(tq), cmake(dr, di));                         // w^H v
+        const c128 th = cmul(tq, whv);
+        s_alpha = cmake(-0.5 * th.x, -0.5 * th.y);
+    }
+    const int r = i + 1 + blockIdx.x * HR + lane;                                // rows <= i of a panel column are never read
+    const int qc = (2 * j + 3) / 4, q0 = wave * qc, q1 = min(2 * j, q0 + qc);
+    c128 p = cmake(0.0, 0.0);
     if (r < n) {
-        c128 w = w0[r];
-        for (int k = 0; k < j; ++k) cfms(w, PV[(long)k * n + r], st[k]);            // V (W^H v)
-        for (int k = 0; k < j; ++k) cfms(w, PW[(long)k * n + r], st[j + k]);        // W (V^H v)
-        w = cmul(tau[i], w);
-        wbuf[r] = w;
-        cfma_conj(dot, w, v[r]);
+        auto term = [&](int q) { return (q < j) ? PV[(long)q * n + r] : PW[(long)(q - j) * n + r]; };
+        int q = q0;
+        for (; q + 8 <= q1; q += 8) {                       // eight terms in flight (see col1)
+            c128 a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = term(q + u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cfma(p, a[u], st[q + u]);
+        }
+        for (; q < q1; ++q) cfma(p, term(q), st[q]);
     }
-    const double dr = block_sum_d(dot.x, sbuf), di = block_sum_d(dot.y, sbuf);
-    if (tid == 0) cpart[blockIdx.x] = cmake(dr, di);
-}
-
-// w += alpha v, alpha = -1/2 tau (w^H v); panel column j of W (zeros for rows <= i)
-__global__ void __launch_bounds__(HT)
-herm_wfin2_kernel(c128* __restrict__ PW, int n, int i, int j, const c128* __restrict__ v, const c128* __restrict__ wbuf,
-                  const c128* __restrict__ cpart, int nparts, const c128* __restrict__ tau)
-{
-    const int r = blockIdx.x * HT + threadIdx.x;
-    if (r >= n) return;
-    c128 w = cmake(0.0, 0.0);
-    if (r > i) {
-        c128 dot = cmake(0.0, 0.0);
-        for (int q = 0; q < nparts; ++q) dot = cadd(dot, cpart[q]);
-        const c128 th = cmul(tau[i], dot);
-        const c128 alpha = cmake(-0.5 * th.x, -0.5 * th.y);
-        w = wbuf[r];
-        cfma(w, alpha, v[r]);
-    }
+    sp[wave][lane] = p;
+    __syncthreads();
+    if (wave != 0 || r >= n) return;
+    const c128 u = csub(w0[r], cadd(cadd(sp[0][lane], sp[1][lane]), cadd(sp[2][lane], sp[3][lane])));
+    c128 w = cmul(tau[i], u);
+    cfma(w, s_alpha, PV[(long)j * n + r]);
     PW[(long)j * n + r] = w;
 }
 
@@ -412,11 +449,11 @@ int maus_herm_tridiag(maus_ctx* c, double* d_out, double* e_out) {
     HermClock clk;
     herm_free(c);
     const size_t nn = (size_t)n * n;
-    c128 *Aw = nullptr, *PV = nullptr, *PW = nullptr, *P2 = nullptr, *Q2 = nullptr, *col = nullptr, *w0 = nullptr, *wbuf = nullptr, *t = nullptr, *cpart = nullptr;
+    c128 *Aw = nullptr, *PV = nullptr, *PW = nullptr, *P2 = nullptr, *Q2 = nullptr, *col = nullptr, *w0 = nullptr, *t = nullptr, *cpart = nullptr;
     double *part = nullptr, *d = nullptr, *e = nullptr;
-    const int nparts_max = (n + HT - 1) / HT;
+    const int nparts_max = (n + HR - 1) / HR;
     auto cleanup = [&]() {
-        void* ps[] = {Aw, PV, PW, P2, Q2, col, w0, wbuf, t, cpart, part, d, e};
+        void* ps[] = {Aw, PV, PW, P2, Q2, col, w0, t, cpart, part, d, e};
         for (void* p : ps) if (p) (void)hipFree(p);
     };
 #define HERM_ALLOC(ptr, bytes) do { if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { (void)hipGetLastError(); cleanup(); herm_free(c); \
@@ -430,9 +467,8 @@ int maus_herm_tridiag(maus_ctx* c, double* d_out, double* e_out) {
     HERM_ALLOC(Q2, sizeof(c128) * (size_t)2 * HNB * n);
     HERM_ALLOC(col, sizeof(c128) * n);
     HERM_ALLOC(w0, sizeof(c128) * n);
-    HERM_ALLOC(wbuf, sizeof(c128) * n);
     HERM_ALLOC(t, sizeof(c128) * 2 * HNB);
-    HERM_ALLOC(cpart, sizeof(c128) * nparts_max);
+    HERM_ALLOC(cpart, sizeof(c128) * ((n + 3) / 4));
     HERM_ALLOC(part, sizeof(double) * nparts_max);
     HERM_ALLOC(d, sizeof(double) * n);
     HERM_ALLOC(e, sizeof(double) * n);
@@ -445,20 +481,23 @@ int maus_herm_tridiag(maus_ctx* c, double* d_out, double* e_out) {
     if (err == hipSuccess) err = hipMemsetAsync(c->htau, 0, sizeof(c128) * n, st);
     if (err == hipSuccess) err = hipMemsetAsync(c->hq, 0, sizeof(c128) * nn, st);
     if (err == hipSuccess) err = hipMemsetAsync(e, 0, sizeof(double) * n, st);
-    for (int i0 = 0; i0 < n && err == hipSuccess; i0 += HNB) {
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (auto& x : ev) if (err == hipSuccess) err = hipEventCreateWithFlags(&x, hipEventDisableTiming);
+    int panel = 0;
+    for (int i0 = 0; i0 < n && err == hipSuccess; i0 += HNB, ++panel) {
         const int nb = (n - i0 < HNB) ? n - i0 : HNB;
+        // at most two panels (~400 launches) in flight
+        if (panel >= 2) err = hipEventSynchronize(ev[panel & 1]);
+        if (err != hipSuccess) break;
         for (int j = 0; j < nb; ++j) {
             const int i = i0 + j, m = n - i, mp = n - i - 1;
-            const int np1 = (m + HT - 1) / HT;
-            hipLaunchKernelGGL(herm_colupd_kernel, dim3(np1), dim3(HT), 0, st, Aw, n, i, j, PV, PW, col, part);
-            hipLaunchKernelGGL(herm_larfg_kernel, dim3(1), dim3(1024), 0, st, col, n, i, j, part, np1, PV, c->hq, c->htau, d, e);
+            const int np1 = (m + HR - 1) / HR;
+            hipLaunchKernelGGL(herm_col1_kernel, dim3(np1), dim3(256), 0, st, Aw, n, i, j, PV, PW, col, part, d);
             if (mp <= 0) continue;
-            const c128* v = PV + (size_t)j * n;
-            hipLaunchKernelGGL(herm_hemv_kernel, dim3((mp + 3) / 4), dim3(256), 0, st, Aw, n, i, v, w0);
-            if (j > 0) hipLaunchKernelGGL(herm_dots_kernel, dim3(2 * j), dim3(HT), 0, st, PV, PW, n, i, j, v, t);
-            const int np2 = (mp + HT - 1) / HT;
-            hipLaunchKernelGGL(herm_wfin1_kernel, dim3(np2), dim3(HT), 0, st, PV, PW, n, i, j, v, w0, t, c->htau, wbuf, cpart);
-            hipLaunchKernelGGL(herm_wfin2_kernel, dim3((n + HT - 1) / HT), dim3(HT), 0, st, PW, n, i, j, v, wbuf, cpart, np2, c->htau);
+            const int nh = (mp + 3) / 4;
+            hipLaunchKernelGGL(herm_col2_kernel, dim3(nh + 2 * j), dim3(256), 0, st, Aw, n, i, j, nh, col, part, np1, PV, PW, c->hq, c->htau, e,
+                               w0, cpart, t);
+            hipLaunchKernelGGL(herm_col3_kernel, dim3((mp + HR - 1) / HR), dim3(256), 0, st, PV, PW, n, i, j, w0, t, c->htau, cpart, nh);
         }
         const int r0 = i0 + nb, M = n - r0;
         if (M > 0) {
@@ -468,7 +507,9 @@ int maus_herm_tridiag(maus_ctx* c, double* d_out, double* e_out) {
             maus_zgemm_launch(st, M, M, 2 * nb, P2, 2 * nb, 0, Q2, 2 * nb, 0, Aw + (size_t)r0 * n + r0, n, 0, -1.0, 1, 1, 1, false, true);
         }
         err = hipGetLastError();
+        if (err == hipSuccess) err = hipEventRecord(ev[panel & 1], st);
     }
+    for (auto& x : ev) if (x) (void)hipEventDestroy(x);
     if (err == hipSuccess && (maus_stage_d2h(c, d_out, d, sizeof(double) * n, st)
                               || (n > 1 && maus_stage_d2h(c, e_out, e, sizeof(double) * (n - 1), st)))) { cleanup(); herm_free(c); return -1; }
     if (err == hipSuccess) err = hipStreamSynchronize(st);

@@ -181,6 +181,22 @@ __device__ unsigned long long g_panel_clk[16];
 // 51.5 vs 53.6 ms per 181-solve sweep, 34.2 vs 30.0 at 32); 1024 threads per workgroup (69 vs 54 ms); one barrier per
 // column with per-wave candidate rows published before it, DPP maximum and pivot rows kept in LDS (67 vs 54 ms: the
 // column step is bound by its instruction count, not by its barriers).
+// physical rows of a thread's logical rows (k is a compile-time constant at every use: the loops are unrolled).  LDS_BACKED: the
+// 16-rows-per-thread variant (m > 4096) keeps them in LDS, [k][thread] as 16-bit entries (npad <= 8192) -- in registers they
+// were what the kernel spilled
+template <int RPT, bool LDS_BACKED> struct PhysRows;
+template <int RPT> struct PhysRows<RPT, false> {
+    int v[RPT];
+    __device__ __forceinline__ PhysRows(unsigned short*) {}
+    __device__ __forceinline__ int get(int k) const { return v[k]; }
+    __device__ __forceinline__ void set(int k, int x) { v[k] = x; }
+};
+template <int RPT> struct PhysRows<RPT, true> {
+    unsigned short* base;
+    __device__ __forceinline__ PhysRows(unsigned short* smem) : base(smem + threadIdx.x) {}
+    __device__ __forceinline__ int get(int k) const { return base[k * PT]; }
+    __device__ __forceinline__ void set(int k, int x) { base[k * PT] = (unsigned short)x; }
+};
 template <int RPT, int PWL>
 __global__ void __launch_bounds__(PT)
 lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long strideH, int j0, int m,
@@ -209,9 +225,10 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
     unsigned long long tclk = wall_clock64();
 #endif
     c128 R[RPT][PWL];
-    int pr[RPT];
+    __shared__ unsigned short s_phys[(RPT >= 16) ? RPT * PT : 1];
+    PhysRows<RPT, (RPT >= 16)> pr(s_phys);
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) { const int r = tid + k * PT; pr[k] = (r < m) ? perm[r] : 0; }
+    for (int k = 0; k < RPT; ++k) { const int r = tid + k * PT; pr.set(k, (r < m) ? perm[r] : 0); }
 
     PCLK(0);
 #pragma unroll
@@ -238,7 +255,7 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         for (int k = 0; k < RPT; ++k) {
             const int r = tid + k * PT;
             if (r < m && r >= c0) {
-                const c128* row = Hm + (long)pr[k] * ld;
+                const c128* row = Hm + (long)pr.get(k) * ld;
                 c128 nw[PWL];
 #pragma unroll
                 for (int c = 0; c < PWL; ++c) nw[c] = row[c0 + c];
@@ -296,12 +313,12 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
                 if (r == p) {
 #pragma unroll
                     for (int cc = 0; cc < PWL; ++cc) s_piv[cc] = R[k][cc];
-                    s_pphys = pr[k];
+                    s_pphys = pr.get(k);
                 }
                 if (r == a && p != a) {
 #pragma unroll
                     for (int cc = 0; cc < PWL; ++cc) s_old[cc] = R[k][cc];
-                    s_aphys = pr[k];
+                    s_aphys = pr.get(k);
                 }
             }
             if (tid == 0) ipiv[a] = j0 + p;
@@ -314,11 +331,11 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
                     if (r == a) {
 #pragma unroll
                         for (int cc = 0; cc < PWL; ++cc) R[k][cc] = s_piv[cc];
-                        pr[k] = s_pphys;
+                        pr.set(k, s_pphys);
                     } else if (r == p) {
 #pragma unroll
                         for (int cc = 0; cc < PWL; ++cc) R[k][cc] = s_old[cc];
-                        pr[k] = s_aphys;
+                        pr.set(k, s_aphys);
                     }
                 }
             }
@@ -351,7 +368,7 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         for (int k = 0; k < RPT; ++k) {
             const int r = tid + k * PT;
             if (r < m && r >= c0) {
-                c128* row = Hm + (long)pr[k] * ld;
+                c128* row = Hm + (long)pr.get(k) * ld;
 #pragma unroll
                 for (int c = 0; c < PWL; ++c) row[c0 + c] = R[k][c];
             }
@@ -360,7 +377,7 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         PCLK(4);
     }
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) { const int r = tid + k * PT; if (r < m) perm[r] = pr[k]; }
+    for (int k = 0; k < RPT; ++k) { const int r = tid + k * PT; if (r < m) perm[r] = pr.get(k); }
     if (tid == 0 && s_info != 0 && info_g[blockIdx.x] == 0) info_g[blockIdx.x] = s_info;
 }
 
@@ -821,15 +838,17 @@ trsm_mfma_kernel(const c128* __restrict__ Hg, c128* __restrict__ Ug, long stride
     const c128* Hs = H + lu_tile_off(npad, col0);                            // this strip's tile column, physical row 0
     c128* Us = U + lu_tile_off(npad, col0) + (long)j * LU_TW;                // this strip's tile column, logical row j
     // the row lists first, then every B tile of the strip: 4 NB loads per lane in flight before the first product
-    unsigned lrow[NB];
-    d4 xr[NB], xi[NB];
+    // (the row offsets of the L fragments wait in LDS, one private slot per lane and block row: eight registers fewer)
+    __shared__ unsigned s_lrow[4][NB][64];
+    // (plain doubles, not d4 vectors: a B operand of the MFMA is any register pair, so the tiles stay where their loads put them)
+    double xr[NB][4], xi[NB][4];
     {
         unsigned prow[NB][4];
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) prow[bi][r] = (unsigned)perm[16 * bi + 4 * r + q] * LU_TW + i16;
-            lrow[bi] = (unsigned)perm[16 * bi + i16] * LU_TW + q;
+            s_lrow[wave][bi][lane] = (unsigned)perm[16 * bi + i16] * LU_TW + q;
         }
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
@@ -843,8 +862,9 @@ trsm_mfma_kernel(const c128* __restrict__ Hg, c128* __restrict__ Ug, long stride
     // A-operand fragments: lane holds block element [row i16][column 4 s + q], s = 0..3
     auto load_l = [&](int bi, int bj, c128 (&f)[4]) {
         const c128* p = H + lu_tile_off(npad, j + 16 * bj);                  // uniform
+        const unsigned lr = s_lrow[wave][bi][lane];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) f[s] = p[lrow[bi] + 4 * s];
+        for (int s = 0; s < 4; ++s) f[s] = p[lr + 4 * s];
     };
     const unsigned drow = (unsigned)i16 * LU_TW + q;
     auto load_d = [&](int bi, c128 (&f)[4]) {          // strictly lower part from memory, unit diagonal, zeros above
@@ -875,30 +895,33 @@ trsm_mfma_kernel(const c128* __restrict__ Hg, c128* __restrict__ Ug, long stride
                 const bool have_next = nbi < NB;
                 if (have_next) load_blk(nbi, nbj, nx);
                 if (!last) {
-                    const d4 xs = xr[bj] + xi[bj];
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s].x, xr[bj][s], s1, 0, 0, 0);
                         s2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s].y, xi[bj][s], s2, 0, 0, 0);
-                        s3 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s].x + cur[s].y, xs[s], s3, 0, 0, 0);
+                        s3 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s].x + cur[s].y, xr[bj][s] + xi[bj][s], s3, 0, 0, 0);
                     }
                 } else {
                     // the zgemm's 3M epilogue (re = P1 - P2, im = (P3 - P1) - P2), subtracted from the B tile
-                    const d4 tr = (bi > 0) ? xr[bi] - (s1 - s2) : xr[bi];
-                    const d4 ti = (bi > 0) ? xi[bi] - ((s3 - s1) - s2) : xi[bi];
-                    const d4 ts = tr + ti;
+                    double tr[4], ti[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        tr[s] = (bi > 0) ? xr[bi][s] - (s1[s] - s2[s]) : xr[bi][s];
+                        ti[s] = (bi > 0) ? xi[bi][s] - ((s3[s] - s1[s]) - s2[s]) : xi[bi][s];
+                    }
                     d4 p1 = zero, p2 = zero, p3 = zero;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s].x, tr[s], p1, 0, 0, 0);
                         p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s].y, ti[s], p2, 0, 0, 0);
-                        p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s].x + cur[s].y, ts[s], p3, 0, 0, 0);
+                        p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s].x + cur[s].y, tr[s] + ti[s], p3, 0, 0, 0);
                     }
-                    xr[bi] = p1 - p2;
-                    xi[bi] = (p3 - p1) - p2;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r) {
+                        xr[bi][r] = p1[r] - p2[r];
+                        xi[bi][r] = (p3[r] - p1[r]) - p2[r];
                         Us[(unsigned)((16 * bi + 4 * r + q) * LU_TW + i16)] = cmake(xr[bi][r], xi[bi][r]);
+                    }
                 }
                 if (have_next) {
 #pragma unroll
@@ -1041,17 +1064,15 @@ static void lu_panel(const LuWs& w, int j0) {
     // only LU in flight on the device (w.mw_sync set) and all G*W workgroups fit on the chip at once -- the workgroups of a
     // matrix wait for each other.
 #if MAUS_NBP == 16
-    // m <= 1024: the whole slice in the registers of one workgroup (MAUS_PANEL_RS=0: the left-looking kernel, measurement)
-    static const int rs_on = [] { const char* e = getenv("MAUS_PANEL_RS"); return e ? atoi(e) : 1; }();
-    if (rs_on && m <= 2 * PT) {
+    // m <= 1024: the whole slice in the registers of one workgroup
+    if (m <= 2 * PT) {
 #define PANEL_RS(NT) hipLaunchKernelGGL((lu_panel_rs_kernel<2, NT>), grid, dim3(NT), 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, j0, m, w.ipiv, w.perm, w.npad, w.info)
         if (m <= 256) PANEL_RS(128); else if (m <= 512) PANEL_RS(256); else PANEL_RS(512);
 #undef PANEL_RS
         prof(w, KC_PANEL, 1, 8.0 * m * NBP * NBP / 2 * w.G, 16.0 * m * NBP * 2 * w.G);
         return;
     }
-    static const int mw_on = [] { const char* e = getenv("MAUS_PANEL_MW"); return e ? atoi(e) : 1; }();
-    if (mw_on && w.mw_sync && m > 1024) {
+    if (w.mw_sync && m > 1024) {
         static const int ncu = [] { int v = 0; int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
         auto p2floor = [](int x) { int p = 1; while (2 * p <= x) p *= 2; return p; };
         auto p2ceil = [](int x) { int p = 1; while (p < x) p *= 2; return p; };
@@ -1069,10 +1090,8 @@ static void lu_panel(const LuWs& w, int j0) {
     }
 #endif
     // 8-column register sub-blocks where the rows per thread allow it (m <= 2048): 24 instead of 40 column reads per panel
-    // (33.0 vs 34.4 ms per 181-solve sweep, 37.5 vs 39.1 at 256; MAUS_PANEL_PW8=0: 4-column sub-blocks everywhere)
-    static const int pw8 = [] { const char* e = getenv("MAUS_PANEL_PW8"); return e ? atoi(e) : 1; }();
-    if (pw8 && rpt <= 4) { if (rpt <= 1) PANEL_IP(1, 8); else if (rpt <= 2) PANEL_IP(2, 8); else PANEL_IP(4, 8); }
-    else if (rpt <= 1) PANEL_IP(1, 4); else if (rpt <= 2) PANEL_IP(2, 4); else if (rpt <= 4) PANEL_IP(4, 4);
+    // (33.0 vs 34.4 ms per 181-solve sweep, 37.5 vs 39.1 at 256, against 4-column sub-blocks everywhere)
+    if (rpt <= 1) PANEL_IP(1, 8); else if (rpt <= 2) PANEL_IP(2, 8); else if (rpt <= 4) PANEL_IP(4, 8);
     else if (rpt <= 8) PANEL_IP(8, 4); else PANEL_IP(16, 2);
 #undef PANEL_IP
     prof(w, KC_PANEL, 1, 8.0 * m * NBP * NBP / 2 * w.G, 16.0 * m * NBP * 8 * w.G);

@@ -572,75 +572,50 @@ void maus_zgemm_launch_rows(hipStream_t st, int M, int N, int K, const c128* A, 
                             const int* a_rows, const int* c_rows, long rows_stride)
 {
     if (M <= 0 || N <= 0 || batch <= 0) return;
-    static const int cfg = [] { const char* e = getenv("MAUS_GEMM_CFG"); return e ? atoi(e) : 0; }();
-    static const int use3m = [] { const char* e = getenv("MAUS_GEMM_3M"); return e ? atoi(e) : 1; }();
 #define ARGS st, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, alpha, beta, batch, blay, conja, conjb, a_rows, c_rows, rows_stride
-    // All kernels: 4 waves per workgroup and registers / LDS small enough for 3-4 INDEPENDENT workgroups per
-    // CU.  Measured on MI355X (tools/gemm_cfg_check.py, gemm_sweep*.py; K=256, 136 matrices, 4M-equivalent
-    // TFLOP/s): every one-workgroup-per-CU shape (128x64 / 128x128, BK 16/32, software-pipelined or not)
-    // stays at 50-59 -- with all waves of a SIMD in one workgroup they run in lockstep and every wait or
-    // barrier of one is a bubble for all; 8-wave workgroups lose to 4-wave ones at equal tile area.
-    if (cfg == 1 && M >= 128) { launch_cfg<128, 64, 16, 4, 2, true, 2>(ARGS); return; }   // reference: pipelined, 1 WG/CU
-    if (blay == 0 && !conja && !conjb && cfg != 2) {
-        // LU trailing updates (plain layout).  Skinny shapes keep the workgroup tile shaped like the
-        // problem so that no MFMA runs on padding.
+    // All kernels: 4 waves per workgroup and registers / LDS small enough for 3-5 INDEPENDENT workgroups per CU.  Measured on
+    // MI355X in rounds 1-3 (profiles/r01_gemm_sweep_configs.txt, r02_zgemm_tile_variants_small_shapes.txt; K = 256, 136 matrices,
+    // 8MNK-equivalent TFLOP/s): every one-workgroup-per-CU shape (128 x 64 / 128 x 128, BK 16 / 32, software-pipelined or not)
+    // stays at 50-59 -- with all waves of a SIMD in one workgroup they run in lockstep and every wait or barrier of one is a
+    // bubble for all; 8-wave workgroups lose to 4-wave ones at equal tile area.  The variants that lost those sweeps are gone.
+    constexpr int DMA_KMIN = 64;
+    if (blay == 0 && !conja && !conjb) {
+        // plain layout (row-major LU workspaces of the GMRES path, host-matrix entry points).  Skinny shapes keep the workgroup
+        // tile shaped like the problem so that no MFMA runs on padding.
         if (N <= 16) { launch_lu_only<128, 16, 16, 4, 1>(ARGS); return; }
         if (M <= 16) { launch_lu_only<16, 128, 16, 1, 4, false, 3>(ARGS); return; }
-        // K >= 64: the LDS-DMA staged 3M kernel.  Measured on MI355X (tools/gemm_k512_check.py, 3584 x 3616 x 512, 136
-        // matrices, 8MNK-equivalent TFLOP/s): register-staged kernel below 79.2; DMA staging, 64 x 32 tiles, five workgroups
-        // per CU (87 VGPRs without the staging registers): 83.6 with the prefetch issued before the fragment reads, **86.8**
-        // with it issued behind them (see the kernel); 64 x 64 tiles at three workgroups per CU **88.7** on large updates
-        // (86.3 at 1024 x 1056: the 64 x 32 form is kept below 1536); six per CU 69 (spills), a ring of three buffers at
-        // four per CU 85.1, 32 x 64 tiles 86.9, the DMA from inline asm 84.1.  Same summation order as the register-staged
-        // kernel, hence the same bits.  The recursion levels K = 128 / 64 gain 8 % / 3 %, K <= 32 nothing.
-        // MAUS_GEMM_DMA=0 switches back.
-        static const int dma = [] { const char* e = getenv("MAUS_GEMM_DMA"); return e ? atoi(e) : 1; }();
-        static const int dma_kmin = [] { const char* e = getenv("MAUS_GEMM_DMA_KMIN"); return e ? atoi(e) : 64; }();
-        if (use3m && dma && M > 32 && (K % 8) == 0 && K >= dma_kmin) {
-            if (dma == 3) launch_dma<3, 4, 2, 1>(ARGS);
-            else if (dma == 44) launch_dma<2, 4, 2, 2>(ARGS);
-            else if (dma == 1 && M >= 1536 && N >= 1536) launch_dma<2, 3, 2, 2>(ARGS);   // 64 x 64 tiles, three workgroups per CU
-            else if (dma == 43) launch_dma<2, 3, 2, 2>(ARGS);          // 64 x 64 tile, 3 workgroups per CU
-            else if (dma == 12) launch_dma<2, 5, 1, 2>(ARGS);          // 32 x 64 tile
+        // K >= 64: the LDS-DMA staged 3M kernel.  3584 x 3616 x 512, 136 matrices: register-staged kernel 79.2; DMA staging,
+        // 64 x 32 tiles, five workgroups per CU 86.8 (prefetch issued behind the fragment reads); 64 x 64 tiles at three
+        // workgroups per CU 88.7 on large updates (86.3 at 1024 x 1056: the 64 x 32 form is kept below 1536).  Same summation
+        // order as the register-staged kernel, hence the same bits.
+        if (M > 32 && (K % 8) == 0 && K >= DMA_KMIN) {
+            if (M >= 1536 && N >= 1536) launch_dma<2, 3, 2, 2>(ARGS);   // 64 x 64 tiles, three workgroups per CU
             else launch_dma<2, 5, 2, 1>(ARGS);
             return;
         }
-        if (use3m) {
-            // 3M complex product: three real MFMA products per complex one (ArBr, AiBi, (Ar+Ai)(Br+Bi))
-            // instead of four.  A 32x16 wave tile keeps the three accumulator planes, the fragments and the
-            // in-flight prefetch of the next K-tile inside 128 VGPRs, so four workgroups still share a CU:
-            // 77 TFLOP/s (4M-equivalent) against 66 for the 4M kernel; other 3M shapes: 64x64 (8 waves) 75,
-            // 32x64 74, 128x32 (8 waves) 71, BK=32 55-60 (with the prefetch really in flight), double-buffered LDS 57-72.
-            // Error is normwise the same as 4M (9.5e-16 vs 1.1e-15 relative on random data); the imaginary
-            // part loses its componentwise bound, which LU with partial pivoting does not rely on.
-            if (cfg == 3) { launch_lu_only<64, 64, 16, 2, 4, false, 2, true>(ARGS); return; }
-            if (M <= 32 || cfg == 8) { launch_lu_only<32, 64, 16, 1, 4, false, 4, true>(ARGS); return; }
-            launch_lu_only<64, 32, 16, 2, 2, false, 4, true>(ARGS); return;
-        }
-        if (N <= 32) { launch_lu_only<128, 32, 16, 4, 1, false, 2>(ARGS); return; }
-        if (M <= 32) { launch_lu_only<32, 128, 16, 1, 4, false, 2>(ARGS); return; }
+        // 3M complex product on the register-staged kernel: three real MFMA products per complex one (ArBr, AiBi,
+        // (Ar+Ai)(Br+Bi)); a 32 x 16 wave tile keeps the three accumulator planes, the fragments and the in-flight prefetch of
+        // the next K-tile inside 128 VGPRs.  Error is normwise the same as 4M (9.5e-16 vs 1.1e-15 relative on random data); the
+        // imaginary part loses its componentwise bound, which LU with partial pivoting does not rely on.
+        if (M <= 32) { launch_lu_only<32, 64, 16, 1, 4, false, 4, true>(ARGS); return; }
+        launch_lu_only<64, 32, 16, 2, 2, false, 4, true>(ARGS); return;
     }
     // Population products with a dot-product B layout and / or conjugated operands: the DMA-staged 3M kernel (round 3) where
-    // its staging applies (K a multiple of 8, >= 64, more than one 32-row tile); MAUS_POPGEMM_3M=0: the 4M kernel below
-    static const int pop3m = [] { const char* e = getenv("MAUS_POPGEMM_3M"); return e ? atoi(e) : 1; }();
-    if (pop3m && use3m && cfg == 0 && (blay != 0 || conja || conjb) && M > 32 && (K % 8) == 0 && K >= 64) {
+    // its staging applies (K a multiple of 8, >= 64, more than one 32-row tile)
+    if (M > 32 && (K % 8) == 0 && K >= DMA_KMIN) {
         if (blay == 1 && !conja && !conjb) { launch_dma_pop<1, false, false>(ARGS); return; }
         if (blay == 1 && conja && !conjb) { launch_dma_pop<1, true, false>(ARGS); return; }
         if (blay == 1 && !conja && conjb) { launch_dma_pop<1, false, true>(ARGS); return; }
         if (blay == 0 && conja && !conjb) { launch_dma_pop<0, true, false>(ARGS); return; }
         if (blay == 0 && !conja && conjb) { launch_dma_pop<0, false, true>(ARGS); return; }
     }
-    // 4M (population matvecs, Hermitian / SVD products, MAUS_GEMM_3M=0): 64x64 tiles, 32x32 wave tile.
-    // With the next K-tile genuinely in flight during the MFMAs this needs ~160 VGPRs: three workgroups per CU.
-    // A population of a few hundred candidates against an n x n matrix gives few such tiles (M = 512, N = 2048: 256 -- one
-    // workgroup on each CU where three fit; M = 300, N = 4096: 320): below two tiles per CU the tile shrinks to 32 x 64 /
-    // 32 x 32 so that the grid covers the chip (MAUS_POPGEMM_TILE = 0 / 1 / 2 forces 64x64 / 32x64 / 32x32).
-    static const int pop_tile = [] { const char* e = getenv("MAUS_POPGEMM_TILE"); return e ? atoi(e) : -1; }();
+    // 4M otherwise (a handful of candidates, K not a multiple of 8): 64 x 64 tiles, 32 x 32 wave tile; with the next K-tile
+    // genuinely in flight during the MFMAs this needs ~160 VGPRs: three workgroups per CU.  A population of a few hundred
+    // candidates against an n x n matrix gives few such tiles (M = 512, N = 2048: 256 -- one workgroup on each CU where three
+    // fit): below two tiles per CU the tile shrinks to 32 x 64 / 32 x 32 so that the grid covers the chip (M = 15 against
+    // 8192 x 8192 runs 0.57 ms per product on 256 workgroups of 32 x 32, 0.86 on 128 of 64 x 64).
     const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * batch;
-    int tile = pop_tile;
-    // (a handful of candidates -- the 15 spawned per iteration of a converged Hermitian population, the tail of a GMRES run --
-    //  follow the same rule: M = 15 against 8192 x 8192 runs 0.57 ms per product on 256 workgroups of 32 x 32, 0.86 on 128 of 64 x 64)
-    if (tile < 0) tile = (t64 >= 512) ? 0 : ((long)((M + 31) / 32) * ((N + 63) / 64) * batch >= 512 ? 1 : 2);
+    const int tile = (t64 >= 512) ? 0 : ((long)((M + 31) / 32) * ((N + 63) / 64) * batch >= 512 ? 1 : 2);
     if (tile == 1) { launch_cfg<32, 64, 16, 1, 4, false, 4>(ARGS); return; }
     if (tile == 2) { launch_cfg<32, 32, 16, 2, 2, false, 4>(ARGS); return; }
     launch_cfg<64, 64, 16, 2, 2, false, 3>(ARGS);
@@ -654,7 +629,7 @@ void maus_zgemm_launch_lu(hipStream_t st, int M, int N, int K, const c128* H, co
                           int acol, int brow, int ccol, int batch, const int* rows, long rows_stride)
 {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return;
-    static const int dma_kmin = [] { const char* e = getenv("MAUS_GEMM_DMA_KMIN"); return e ? atoi(e) : 64; }();
+    constexpr int dma_kmin = 64;
     const TCol tc{acol, brow, ccol};
 #define ARGS st, M, N, K, H, nrows, stride, U, nrows, stride, Hc, nrows, stride, -1.0, 1, batch, 0, false, false, rows, rows, rows_stride, tc
     if (N <= 16) { launch_lu_only<128, 16, 16, 4, 1, false, 4, false, true>(ARGS); return; }

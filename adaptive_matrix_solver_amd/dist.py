@@ -105,6 +105,10 @@ def _exchange_unique_id(rank: int, world: int, make_id, timeout: float = 300.0) 
     raise RuntimeError(f"dist: rank {rank} could not fetch the RCCL id from rank 0 on {addr}:{ports[0]}..{ports[-1]}")
 
 
+class RootFailure(RuntimeError):
+    """Work that one rank does for all of them (start-up diagnostics, the Hermitian decomposition) failed there."""
+
+
 class PopulationComm:
     """rank / world, the block partition, and the collectives of a sharded run.  `transport`: 'rccl' or 'gloo'."""
 
@@ -212,19 +216,38 @@ class PopulationComm:
         self.bcast_array(buf, root)
         return obj if self.rank == root else pickle.loads(buf.tobytes())
 
+    def root_call(self, fn, root: int = 0):
+        """fn() on `root` only, its (picklable) result on every rank.  Whatever fn raises on the root -- a device allocation
+        that fails, MemoryError, an error of the library -- is raised on EVERY rank as RootFailure: the status travels first,
+        so no rank is left waiting inside a collective that the root never enters."""
+        status = None
+        if self.rank == root:
+            try:
+                status = ("ok", fn())
+            except Exception as e:                                  # noqa: BLE001 -- the point is that nothing escapes un-broadcast
+                status = ("err", f"{type(e).__name__}: {e}")
+        status = self.bcast_object(status, root)
+        if status[0] != "ok":
+            raise RootFailure(f"rank {root} failed in work it does for all ranks: {status[1]}")
+        return status[1]
+
     def bcast_eigvecs(self, ctx, evecs, n: int, root: int = 0) -> None:
         """The eigenvector matrix of the Hermitian shortcut (AMS:161): decomposed by `root` only, resident on every rank
-        afterwards.  rccl: uploaded once and broadcast device to device; gloo: host broadcast, then each rank uploads."""
+        afterwards.  rccl: uploaded once and broadcast device to device; gloo: host broadcast, then each rank uploads.  The
+        root's own preparation (an upload or a read-back of n x n) runs under root_call: its failure reaches every rank."""
         if self.transport == "rccl":
             t0 = time.perf_counter()
-            if self.rank == root and evecs is not None:      # None: already resident on the root's device (device_eigh)
-                ctx.set_eigvecs(evecs)
+            # evecs None: already resident on the root's device (device_eigh)
+            self.root_call(lambda: ctx.set_eigvecs(evecs) if evecs is not None else None, root)
             self._need_ctx().comm_bcast_eigvecs(n, root)
             self._account(t0, 16 * n * n)
             return
-        if self.rank == root and evecs is None:
-            evecs = ctx.get_eigvecs()
-        V = np.ascontiguousarray(evecs, dtype=np.complex128) if self.rank == root else np.empty((n, n), dtype=np.complex128)
+        held = {}
+
+        def fetch():
+            held["V"] = np.ascontiguousarray(evecs if evecs is not None else ctx.get_eigvecs(), dtype=np.complex128)
+        self.root_call(fetch, root)
+        V = held["V"] if self.rank == root else np.empty((n, n), dtype=np.complex128)
         self.bcast_array(V.view(np.float64), root)
         ctx.set_eigvecs(V)
 

@@ -593,6 +593,7 @@ class DeviceEngine:
         import scipy.linalg as sla
         self.bind_matrix(A)
         d, e = self.ctx.herm_tridiag()
+        self.tridiag_de = (d, e)               # the real tridiagonal T (diagnostics and tests)
         n = A.shape[0]
         if n == 1:
             self.ctx.herm_backtransform(np.ones((1, 1)))
@@ -632,21 +633,23 @@ class DeviceEngine:
                 return None, str(e)
             self.ctx.set_eigvecs(evecs)
             return evals, None
-        evals, evecs, err = np.empty(n, dtype=np.float64), None, ""
-        if comm.rank == 0:
+        held = {}
+
+        def decompose():
+            # LinAlgError is the reference's own failure mode (AMS:180: the candidates fall back to the iteration) and travels
+            # as a result; anything else that stops rank 0 here is raised on every rank by root_call
             try:
                 with comm.all_blas_threads():
                     if dev:
-                        ev = self.device_eigh(A)                   # V stays on rank 0's device; broadcast from there
-                    else:
-                        ev, evecs = sla.eigh(A)
-                evals[:] = ev
+                        return "", self.device_eigh(A)             # V stays on rank 0's device; broadcast from there
+                    ev, held["evecs"] = sla.eigh(A)
+                    return "", ev
             except np.linalg.LinAlgError as e:
-                err = str(e) or "eigh failed"
-        err = comm.bcast_object(err)
+                return str(e) or "eigh failed", None
+        err, ev = comm.root_call(decompose)
         if err:
             return None, err
-        comm.bcast_array(evals)
+        evals, evecs = np.ascontiguousarray(ev, dtype=np.float64), held.get("evecs")
         comm.bcast_eigvecs(self.ctx, evecs, n)
         return evals, None
 
@@ -1090,24 +1093,32 @@ class DeviceEngine:
         thr = strat.get("current_convergence_threshold", CONVERGENCE_RESIDUAL_TOL)
         self._stage_history(cands)
         prev = np.array([c.prev_residual for c in cands], dtype=np.float64)
-        alpha = np.array([c.alpha_local_step.real for c in cands], dtype=np.float64)      # np.complex128(0.01) in the reference (AMS:17): the imaginary part is always 0
+        # alpha is np.complex128(0.01) in the reference (AMS:17, imaginary part always 0) and keeps that type through
+        # `alpha * 1.1` etc. until a clamp hands back the Python-float bound (AMS:308, 311, 314: min / max return one of their
+        # arguments; NumPy orders complex scalars lexicographically) or convergence sets 0.0 (AMS:331); from then on it is a
+        # Python float.  The arithmetic is done on arrays, the types are restored per candidate below.
+        alpha_old = [c.alpha_local_step for c in cands]
+        alpha = np.array([a.real for a in alpha_old], dtype=np.float64)
         with np.errstate(invalid="ignore", over="ignore"):
             live = prev > 1e-10                                                  # AMS:306
             m1 = live & (resv < prev * 0.9)                                      # AMS:307 -> REFINING
             m2 = live & ~m1 & (resv > prev * 1.5) & (prev > 1e-5)                # AMS:310 -> STUCK
             m3 = live & ~m1 & ~m2                                                # AMS:313 -> EXPLORING
-            new_alpha = np.where(m1, np.minimum(alpha * 1.1, 1.0),
-                                 np.where(m2, np.maximum(alpha * 0.5, 1e-6), np.maximum(alpha * 0.95, 1e-6)))
+            raw = np.where(m1, alpha * 1.1, np.where(m2, alpha * 0.5, alpha * 0.95))
+            clamped = np.where(m1, raw > 1.0, raw < 1e-6)                        # min(x, 1.0) is 1.0 iff 1.0 < x; max(x, 1e-6) is 1e-6 iff x < 1e-6
+            new_alpha = np.where(clamped, np.where(m1, 1.0, 1e-6), raw)
             conv = (resv < thr) & okv                                            # AMS:318-331
         code = (m1 * 1 + m2 * 2 + m3 * 3).tolist()
         new_alpha = new_alpha.tolist()
+        clamped = clamped.tolist()
+        c128 = np.complex128
         conv = conv.tolist()
         CONV, STUCK, RETIRED = S.CONVERGED, S.STUCK, S.RETIRED
         for k, c in enumerate(cands):
             c._record_history()                                          # AMS:303-304
             cd = code[k]
             if cd:
-                c.alpha_local_step = new_alpha[k]
+                c.alpha_local_step = new_alpha[k] if (clamped[k] or type(alpha_old[k]) is not c128) else c128(new_alpha[k])
                 st = c.state
                 if cd == 1:
                     if st is not CONV:

@@ -461,12 +461,14 @@ class MAUS_Solver:
             # for a Hermitian eigenproblem, the eigh the shortcut needs anyway) with the node's BLAS threads, and broadcasts
             # the result: N ranks must not repeat an O(n^3) host computation, and the strategy -- with it the sequence of
             # collectives -- cannot diverge between ranks.
-            di = None
-            if comm.rank == 0:
+            # (root_call: an exception on rank 0 -- device memory for the decomposition, MemoryError for an embedding -- is
+            # raised on every rank instead of leaving the others inside the broadcasts that follow)
+            def diagnose():
                 with comm.all_blas_threads():
                     di = self._diagnose_matrix_initial(self.M)
                 di["_eigh_seed"] = "_eigh_seed" in self.__dict__
-            self.diag_info = comm.bcast_object(di)
+                return di
+            self.diag_info = comm.root_call(diagnose)
             if self.diag_info.pop("_eigh_seed", False):
                 self.engine.bind_matrix(self.M)
                 seed = self.__dict__.pop("_eigh_seed", None)

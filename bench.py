@@ -272,8 +272,8 @@ def run_other_config(args):
     d = prof[dom]
     if dom in gemm_classes:
         # LU trailing updates and (since round 3) the population products run the 3M kernel: 6 M N K executed per complex GEMM
-        use3m = os.environ.get("MAUS_GEMM_3M", "1") != "0" and (kind == "eig" or os.environ.get("MAUS_POPGEMM_3M", "1") != "0")
-        exec_ratio = 0.75 if use3m else 1.0
+        use3m = True
+        exec_ratio = 0.75
         alg = d["flops"] / max(1e-12, d["ms"] * 1e-3) / 1e12
         what = "3M LU trailing-update zgemm" if kind == "eig" else f"{'3M' if use3m else '4M'} population zgemm: A@X / A^H U / conj(X) V"
         roof = {"bound": "mfma", "kernel": f"{dom} ({what}, v_mfma_f64_16x16x4_f64)",
@@ -520,8 +520,7 @@ def main():
         gk = [k for k in prof if k.startswith("zgemm")]
         g = dict(prof["zgemm"])
         tot_ms = sum(v["ms"] for v in prof.values())
-        use3m = os.environ.get("MAUS_GEMM_3M", "1") != "0"
-        exec_ratio = 0.75 if use3m else 1.0       # real flops executed on the matrix pipe / algorithmic 8MNK
+        exec_ratio = 0.75       # real flops executed on the matrix pipe / algorithmic 8MNK (3M complex products)
         # rate = flops of the bracketed K>=256 launches / time during which at least one of them was executing (the
         # union of their intervals over both sub-batch streams).  Two trailing updates running side by side share the
         # machine: the plain sum of their event-to-event durations would count that time twice, and a sample's duration
@@ -635,7 +634,7 @@ def main():
             "step_frac_of_mfma_peak": (8.0 / 3.0 * n ** 3 + 24.0 * n * n) * steps_done / elapsed / 1e12 / FP64_MFMA_PEAK_TFLOPS,
             # the same in the convention of roofline.frac: flops EXECUTED on the matrix pipe (the LU's 8/3 n^3 run as 3M
             # products, 0.75 of them; the 24 n^2 of the population products as 4M)
-            "step_frac_of_mfma_peak_executed": ((0.75 if os.environ.get("MAUS_GEMM_3M", "1") != "0" else 1.0) * 8.0 / 3.0 * n ** 3 + 24.0 * n * n)
+            "step_frac_of_mfma_peak_executed": (0.75 * 8.0 / 3.0 * n ** 3 + 24.0 * n * n)
                                                * steps_done / elapsed / 1e12 / FP64_MFMA_PEAK_TFLOPS,
             "small_batch_rates": small,
         }

@@ -304,10 +304,6 @@ int maus_profile_read(maus_ctx* ctx, int klass, int* launches, double* total_ms,
 int maus_profile_union_ms(maus_ctx* ctx, int klass, double* union_ms);
 int maus_sync(maus_ctx* ctx);
 
-/* Device-resident timing of the batched LU-update GEMM shape (C[M,N] -= A[M,K] B[K,N] on `batch` matrices
- * embedded in row-major arrays of leading dimension ld, random data): average ms per launch over `iters`. */
-int maus_zgemm_bench(maus_ctx* ctx, int M, int N, int K, int ld, int batch, int iters, float* ms_out);
-
 /* ---- legacy NumPy MT19937 stream helpers (host side) ----- */
 /* Advance a 624-word MT19937 key + position by `nwords` 32-bit outputs without
  * materialising them (GF(2) jump polynomial; cached per nwords). */

@@ -104,6 +104,56 @@ def test_three_and_eight_ranks_equal_single_process(world, name, iters):
         assert [g["eigh_calls"] for g in got] == [1] + [0] * (world - 1)
 
 
+def _failing_worker(rank, world, port, where, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path[:0] = [ROOT, os.path.join(HERE, "golden"), HERE]
+    from adaptive_matrix_solver_amd.dist import PopulationComm, RootFailure
+    from adaptive_matrix_solver_amd import solver as sv
+    from adaptive_matrix_solver_amd import engine as en
+    import scenarios
+    from fake_ctx import FakeContext
+    comm = PopulationComm("gloo")
+    if rank == 0 and where == "diagnosis":
+        def boom(self, M):
+            raise MemoryError("no room for the (2n)^2 embedding")
+        sv.MAUS_Solver._diagnose_matrix_initial = boom
+    if rank == 0 and where == "eigh":
+        import scipy.linalg as sla
+        def boom(*a, **k):
+            raise RuntimeError("hipMalloc failed: out of device memory")
+        sla.eigh = boom
+    what = "finished"
+    try:
+        spec = scenarios.TRAJECTORIES["herm16"]
+        A, _b = scenarios.build(spec)
+        np.random.seed(spec["seed"]); random.seed(spec["seed"]); sv.SolutionCandidate._candidate_id_counter = 0
+        eng = en.DeviceEngine(ctx=FakeContext(), pert_mode="uniform", gmres_compat="scipy-legacy", comm=comm)
+        solver = sv.MAUS_Solver(A, sv.ProblemType.EIGENVALUE, initial_num_candidates=spec["P"], global_convergence_tol=spec["tol"],
+                                quiet=True, engine=eng, comm=comm)          # the sharded construction: rank 0 alone diagnoses
+        solver.loop_body(1)
+    except RootFailure as e:
+        what = f"RootFailure: {e}"
+    with open(os.path.join(outdir, f"rank{rank}.txt"), "w") as f:
+        f.write(what)
+    dist.barrier()                                     # every rank is still in step: nobody hangs in a broadcast
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("where", ["diagnosis", "eigh"])
+def test_failure_of_rank0_only_work_reaches_every_rank(where):
+    """rank 0 alone diagnoses the matrix and decomposes a Hermitian one; an exception there other than LinAlgError
+    used to skip the broadcasts the other ranks were already waiting in.  Now every rank raises the same RootFailure."""
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_failing_worker, args=(3, _free_port(), where, d), nprocs=3, join=True)
+        got = [open(os.path.join(d, f"rank{r}.txt")).read() for r in range(3)]
+    assert all(g.startswith("RootFailure: rank 0 failed") for g in got), got
+    assert ("MemoryError" if where == "diagnosis" else "out of device memory") in got[1]
+    assert got[0] == got[1] == got[2]
+
+
 def test_owner_partition_is_contiguous_and_balanced():
     from adaptive_matrix_solver_amd.dist import PopulationComm
 

@@ -42,7 +42,7 @@ def _extra_scenarios():
         scenarios.TRAJECTORIES.pop(k, None)
 
 
-from test_gpu_evolve_horizon import EVOLVE_LAP8_ITERS        # derived on the CPU: tests/test_rounding_sensitivity.py
+from rounding import EVOLVE_LAP8_ITERS        # derived on the CPU: tests/test_rounding_sensitivity.py
 
 
 @pytest.mark.parametrize("name,iters", [("eig96", 10), ("lap8", EVOLVE_LAP8_ITERS), ("svd5x4", 30), ("lin24", 12)])

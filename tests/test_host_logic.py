@@ -169,3 +169,41 @@ def test_evolve_reports_like_the_reference(capsys):
     # every reported eigenpair is one: residuals at rounding level
     res = [float(l.split("Res=")[1]) for l in out.splitlines() if l.startswith("  Eig ")]
     assert res and max(res) < 1e-10
+
+
+FLOAT_ALPHA = {"lap8", "eig48u", "svd5x4"}
+
+
+@pytest.mark.parametrize("name,iters", [("eig16", 10), ("lap8", 40), ("eig48u", 26), ("lin24", 8), ("svd5x4", 10)])
+def test_alpha_local_step_keeps_the_reference_types(name, iters):
+    """AMS:124, 308-314, 331: alpha is np.complex128 until a clamp returns the Python-float bound or
+    convergence assigns 0.0.  The oracle keeps the reference's expressions verbatim, so its types are the reference's; compared
+    as type(), not as complex() -- which is blind to the difference."""
+    from oracle import maus_oracle as orc
+    spec = scenarios.TRAJECTORIES[name]
+    A, b = scenarios.build(spec)
+    orc.seed_all(spec["seed"])
+    kind = {"eig": orc.EIGENVALUE, "lin": orc.SOLVE_LINEAR_SYSTEM, "svd": orc.SVD}[spec["kind"]]
+    pop = orc.new_population(A, kind, b=b, n_cands=spec["P"], tol=spec["tol"])
+    ref = []
+    for _ in range(iters):
+        orc.update_diagnostics(pop)
+        orc.adjust_strategy(pop)
+        for c in pop.cands:
+            if c.state not in (orc.CONVERGED, orc.RETIRED):
+                orc.candidate_step(c, pop.M, pop.b, pop.strat, pop.know, gmres_mode="scipy-legacy")
+        ref.append([(c.cid, type(c.alpha), complex(c.alpha)) for c in pop.cands])
+        orc.manage_candidates(pop)
+    solver, _ = make_solver(name)
+    seen = set()
+    for it in range(iters):
+        solver._update_global_diagnostics(it + 1)
+        solver._adjust_global_strategy(it + 1)
+        solver.step_population()
+        got = [(c.id, type(c.alpha_local_step), complex(c.alpha_local_step)) for c in solver.candidates]
+        assert got == ref[it], f"iteration {it + 1}"
+        seen |= {t for _, t, _ in got}
+        solver._manage_candidates(it + 1)
+    assert np.complex128 in seen
+    if name in FLOAT_ALPHA:
+        assert float in seen            # a clamp or a convergence happened: the comparison above saw both kinds

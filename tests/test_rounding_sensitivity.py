@@ -50,7 +50,7 @@ def test_lap8_evolve_horizon_follows_from_the_perturbed_oracle():
     """tests/test_gpu_evolve.py compares the end state of evolve() on `lap8` (30 candidates).  With one ulp in H the oracle
     itself keeps its bookkeeping and survivor order for 45+ iterations and loses them before 60; the evolve test runs
     EVOLVE_LAP8_ITERS iterations, inside that window with DEVICE_ULPS of margin (1.65^4 ~ 8: four iterations earlier)."""
-    from test_gpu_evolve_horizon import EVOLVE_LAP8_ITERS
+    from rounding import EVOLVE_LAP8_ITERS
     env, first_int, first_order = rounding.envelope("lap8", 60, seeds=(1, 2, 3))
     assert 44 <= first_order < 60, first_order
     assert first_int >= first_order

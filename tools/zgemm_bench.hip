@@ -1,0 +1,53 @@
+// Device-resident timing of the batched LU-update GEMM shape (measurement tool, not part of libmaus_hip: until round 3 this was
+// an entry point of the product's C ABI).  C[M,N] -= A[M,K] B[K,N] on `batch` matrices, each embedded in one row-major array of
+// leading dimension ld like the round-1 LU workspace (A = rows K.., cols 0..K; B = rows 0..K, cols K..; C = rows K.., cols K..).
+//
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/bin/zgemm_bench tools/zgemm_bench.hip
+//   tools/bin/zgemm_bench M N K ld batch [iters] [zero] [shared]
+//       zero    all-zero operands (clock check: the chip holds a higher clock on zeros)
+//       shared  every matrix reads the same A and B (traffic check)
+// Prints ms per launch and 8MNK-equivalent TFLOP/s.  The kernels come straight from the library's translation unit.
+#include "../adaptive_matrix_solver_amd/csrc/zgemm.hip"
+#include <cstdio>
+#include <cstring>
+
+__global__ void fill_rand_kernel(double* p, size_t n, unsigned seed) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) { unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; p[i] = (double)(x & 0xffffff) / 16777216.0 - 0.5; }
+}
+
+#define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 6) { fprintf(stderr, "usage: %s M N K ld batch [iters] [zero] [shared]\n", argv[0]); return 2; }
+    const int M = atoi(argv[1]), N = atoi(argv[2]), K = atoi(argv[3]), ld = atoi(argv[4]), batch = atoi(argv[5]);
+    const int iters = argc > 6 ? atoi(argv[6]) : 5;
+    bool zero = false, shared = false;
+    for (int i = 7; i < argc; ++i) { zero |= !strcmp(argv[i], "zero"); shared |= !strcmp(argv[i], "shared"); }
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || iters <= 0 || ld < (N > K ? N : K) + K) { fprintf(stderr, "bad sizes\n"); return 2; }
+    const size_t per = (size_t)((long)M + K) * ld;
+    c128* base = nullptr;
+    CK(hipMalloc((void**)&base, sizeof(c128) * per * batch));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    if (zero) CK(hipMemsetAsync(base, 0, sizeof(c128) * per * batch, st));
+    else hipLaunchKernelGGL(fill_rand_kernel, dim3(2048), dim3(256), 0, st, (double*)base, per * batch * 2, 12345u);
+    const long sAB = shared ? 0 : (long)per;
+    auto launch = [&]() {
+        maus_zgemm_launch(st, M, N, K, base + (size_t)K * ld, ld, sAB, base + K, ld, sAB, base + (size_t)K * ld + K, ld, (long)per,
+                          -1.0, 1, batch, 0, false, false);
+    };
+    launch();
+    CK(hipStreamSynchronize(st));
+    hipEvent_t t0, t1; CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
+    CK(hipEventRecord(t0, st));
+    for (int i = 0; i < iters; ++i) launch();
+    CK(hipEventRecord(t1, st));
+    CK(hipEventSynchronize(t1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, t0, t1));
+    ms /= iters;
+    CK(hipGetLastError());
+    printf("M=%d N=%d K=%d ld=%d batch=%d%s%s: %.3f ms per launch, %.1f TFLOP/s (8MNK)\n", M, N, K, ld, batch, zero ? " zero" : "", shared ? " shared" : "",
+           ms, 8.0 * M * N * K * batch / (ms * 1e-3) / 1e12);
+    (void)hipFree(base);
+    return 0;
+}
