@@ -18,11 +18,11 @@ SYMBOLS = [
     "maus_ctx_create", "maus_ctx_destroy", "maus_last_error", "maus_device_info", "maus_abi_version",
     "maus_set_matrix", "maus_set_rhs", "maus_pop_reserve", "maus_pop_capacity", "maus_pop_put", "maus_pop_get", "maus_pop_copy", "maus_pop_device_ptr", "maus_hist_append", "maus_hist_get", "maus_hist_clear", "maus_hist_generation",
     "maus_matvec_rayleigh", "maus_shifted_lu_solve", "maus_lu_reserve", "maus_lu_workspace_allocs", "maus_set_shared_device", "maus_lu_mw_aborts", "maus_relax_normalise", "maus_residual",
-    "maus_svd_power_step", "maus_svd_power_propose", "maus_svd_commit", "maus_set_eigvecs", "maus_herm_match", "maus_herm_tridiag", "maus_herm_tridiag_eig", "maus_herm_tridiag_eigvals", "maus_herm_backtransform", "maus_get_eigvecs", "maus_gmres", "maus_gmres_pert", "maus_jacobi_check",
+    "maus_svd_power_step", "maus_svd_power_propose", "maus_svd_commit", "maus_set_eigvecs", "maus_herm_match", "maus_herm_tridiag", "maus_herm_release", "maus_herm_tridiag_eig", "maus_herm_tridiag_eigvals", "maus_herm_backtransform", "maus_get_eigvecs", "maus_gmres", "maus_gmres_pert", "maus_jacobi_check",
     "maus_profile_union_ms", "maus_gram", "maus_zgemm_host", "maus_lu_solve_host", "maus_timer_start", "maus_timer_stop",
     "maus_profile_enable", "maus_profile_read", "maus_sync", "maus_mt19937_jump",
     "maus_device_count", "maus_comm_unique_id", "maus_comm_init", "maus_comm_destroy", "maus_comm_info",
-    "maus_comm_allgather_records", "maus_comm_allgather_rows", "maus_comm_bcast", "maus_comm_bcast_eigvecs", "maus_comm_stats",
+    "maus_comm_allgather_records", "maus_comm_allgather_rows", "maus_comm_bcast", "maus_comm_bcast_eigvecs", "maus_comm_set_matrix", "maus_comm_stats",
 ]
 
 COMM_ID_BYTES = 128
@@ -92,6 +92,7 @@ def load_library():
         "maus_set_eigvecs": ([vp, vp, C.c_int], C.c_int),
         "maus_herm_match": ([vp, vp, C.c_int, vp, vp], C.c_int),
         "maus_herm_tridiag": ([vp, vp, vp], C.c_int),
+        "maus_herm_release": ([vp], C.c_int),
         "maus_herm_backtransform": ([vp, vp, C.c_int], C.c_int),
         "maus_herm_tridiag_eig": ([vp, vp, vp, C.c_int, vp, vp], C.c_int),
         "maus_herm_tridiag_eigvals": ([vp, vp, vp, C.c_int, vp], C.c_int),
@@ -118,6 +119,7 @@ def load_library():
         "maus_comm_allgather_rows": ([vp, C.c_int, vp, vp, C.c_int], C.c_int),
         "maus_comm_bcast": ([vp, vp, C.c_size_t, C.c_int], C.c_int),
         "maus_comm_bcast_eigvecs": ([vp, C.c_int, C.c_int], C.c_int),
+        "maus_comm_set_matrix": ([vp, vp, C.c_int, C.c_int, C.c_int], C.c_int),
         "maus_comm_stats": ([vp, C.POINTER(C.c_long), dp, dp, C.c_int], C.c_int),
     }
     for name, (args, res) in sig.items():
@@ -388,6 +390,10 @@ class Context:
         s = 2.0 ** int(np.floor(np.log2(t))) if t > 0.0 else 1.0           # a power of two: the scaling is exact
         return n, d / s, np.ascontiguousarray(e / s if n > 1 else np.zeros(1)), s
 
+    def herm_release(self):
+        """Hand back the reflector store of herm_tridiag (n x n) when no back-transformation will follow."""
+        self._ck(self.lib.maus_herm_release(self.h), "maus_herm_release")
+
     def herm_tridiag_eigvals(self, d, e):
         """Eigenvalues (ascending) of the real symmetric tridiagonal T = (d, e) by bisection on the device."""
         n, ds, es, s = self._scaled_tridiagonal(d, e)
@@ -512,6 +518,16 @@ class Context:
         assert arr.flags["C_CONTIGUOUS"]
         self._ck(self.lib.maus_comm_bcast(self.h, _ptr(arr), arr.nbytes, int(root)), "maus_comm_bcast")
         return arr
+
+    def comm_set_matrix(self, A, rank, root=0, resident_on_root=False):
+        """set_matrix of a sharded run: `root` uploads A (or, resident_on_root, broadcasts the copy its device already
+        holds), the other ranks receive it device to device (only the shape of their A is read)."""
+        upload = rank == root and not resident_on_root
+        if upload:
+            A = _c128(A)
+        self._ck(self.lib.maus_comm_set_matrix(self.h, _ptr(A) if upload else None, A.shape[0], A.shape[1], int(root)),
+                 "maus_comm_set_matrix")
+        self.rows, self.cols = A.shape
 
     def comm_bcast_eigvecs(self, n, root=0):
         self._ck(self.lib.maus_comm_bcast_eigvecs(self.h, int(n), int(root)), "maus_comm_bcast_eigvecs")

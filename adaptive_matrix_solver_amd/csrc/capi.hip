@@ -123,12 +123,24 @@ int maus_h2d(maus_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t 
     if (bytes == 0) return 0;
     if (bytes > STAGE_DIRECT_MAX) return maus_stage_h2d(c, dst, src, bytes, st);
     if (maus_pin_ready(c)) { HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); return 0; }
+    // The ring is reused in two halves, each guarded by an event: before a half is written again, the event recorded behind the
+    // last upload of its previous lap is waited for.  Every entry point synchronises its streams long before 2 MiB of small
+    // uploads are out, so these waits never block on today's paths -- but nothing else enforced that.
     const size_t need = (bytes + 63) & ~(size_t)63;
-    if (c->pin_small_off + need > SMALL_RING) c->pin_small_off = 0;
-    char* slot = c->pin_small + c->pin_small_off;
-    c->pin_small_off += need;
+    for (auto& e : c->pin_small_ev) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (c->pin_small_off + need > SMALL_RING) {                      // wrap: the second half is complete, the first is entered
+        HIPCHK(c, hipEventRecord(c->pin_small_ev[1], st));
+        if (c->pin_small_lap > 0 || c->pin_small_mid) HIPCHK(c, hipEventSynchronize(c->pin_small_ev[0]));
+        c->pin_small_off = 0; c->pin_small_lap++; c->pin_small_mid = false;
+    }
+    const size_t before = c->pin_small_off;
+    const bool crossing = before < SMALL_RING / 2 && before + need >= SMALL_RING / 2;
+    if (crossing && c->pin_small_lap > 0) HIPCHK(c, hipEventSynchronize(c->pin_small_ev[1]));     // the second half is entered
+    char* slot = c->pin_small + before;
+    c->pin_small_off = before + need;
     memcpy(slot, src, bytes);
     HIPCHK(c, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, st));
+    if (crossing) { HIPCHK(c, hipEventRecord(c->pin_small_ev[0], st)); c->pin_small_mid = true; }    // the first half is complete
     return 0;
 }
 // complete on return (the destination is filled by a memcpy from the pinned buffer)
@@ -222,6 +234,7 @@ int maus_ctx_destroy(maus_ctx* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pin_small) (void)hipHostFree(c->pin_small);
+    for (auto e : c->pin_small_ev) if (e) (void)hipEventDestroy(e);
     for (auto ev : c->pin_ev) if (ev) (void)hipEventDestroy(ev);
     hist_free(c);
     for (auto& kv : c->mt_taps) if (kv.second.first) (void)hipFree(kv.second.first);
@@ -261,8 +274,12 @@ static void free_population(maus_ctx* c) {
     c->cap = 0; c->ldp = 0;
 }
 
-int maus_set_matrix(maus_ctx* c, const double* a, int rows, int cols) {
-    if (!a || rows <= 0 || cols <= 0) FAIL(c, "maus_set_matrix: bad arguments");
+}   // extern "C"
+
+// room for a rows x cols problem matrix; everything that belonged to the previous one goes (also called by comm.hip for the
+// ranks that receive the matrix device to device)
+int maus_matrix_reserve(maus_ctx* c, int rows, int cols) {
+    if (rows <= 0 || cols <= 0) FAIL(c, "maus_set_matrix: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->st));
     if (rows != c->rows || cols != c->cols) {
@@ -274,6 +291,14 @@ int maus_set_matrix(maus_ctx* c, const double* a, int rows, int cols) {
     }
     if (c->hq) { (void)hipFree(c->hq); c->hq = nullptr; } if (c->htau) { (void)hipFree(c->htau); c->htau = nullptr; } c->hqn = 0;   // reflectors of the previous matrix
     if (c->hz) { (void)hipFree(c->hz); c->hz = nullptr; c->hzn = 0; }
+    return 0;
+}
+
+extern "C" {
+
+int maus_set_matrix(maus_ctx* c, const double* a, int rows, int cols) {
+    if (!a) FAIL(c, "maus_set_matrix: bad arguments");
+    if (maus_matrix_reserve(c, rows, cols)) return -1;
     return maus_stage_h2d(c, c->A, a, sizeof(c128) * (size_t)rows * cols, c->st);
 }
 

@@ -16,7 +16,16 @@
 #include <vector>
 
 #include "ctx.h"
+// Types only: every call goes through dlsym.  Without the RCCL development headers the few declarations the calls need are
+// spelled out here (they are part of NCCL's stable C ABI), so that the library still builds.
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
+#endif
 
 namespace {
 
@@ -237,6 +246,38 @@ int maus_comm_bcast_eigvecs(maus_ctx* c, int n, int root) {
     if (c->comm_rank == root) { if (!c->V || c->vn != n) FAIL(c, "maus_comm_bcast_eigvecs: root has no eigenvectors (maus_set_eigvecs)"); }
     else if (n != c->vn) { if (c->V) (void)hipFree(c->V); c->V = nullptr; c->vn = 0; HIPCHK(c, hipMalloc((void**)&c->V, bytes)); c->vn = n; }
     NCCLCHK(c, rccl()->Broadcast(c->V, c->V, bytes, ncclChar, root, (ncclComm_t)c->comm, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
+// The problem matrix of a sharded run (A replicated on every GPU): `root` alone uploads it from the host -- one staged
+// copy through one pinned buffer instead of one per rank, 8 x 1 GiB at n = 8192 -- and the others receive it device to device.
+// The root's outcome travels first (one word): an upload that fails there fails this call on every rank instead of leaving
+// the others inside a broadcast the root never enters.  `a` is read on the root only; NULL there = the matrix of that shape is
+// already resident on the root's device (its start-up diagnostics put it there) and is broadcast as it is.
+int maus_comm_set_matrix(maus_ctx* c, const double* a, int rows, int cols, int root) {
+    if (!c->comm) FAIL(c, "maus_comm_set_matrix: no communicator (maus_comm_init)");
+    if (rows <= 0 || cols <= 0 || root < 0 || root >= c->comm_world) FAIL(c, "maus_comm_set_matrix: bad arguments");
+    const size_t bytes = sizeof(c128) * (size_t)rows * cols;
+    Timer tm(c, (double)bytes);
+    int rc;
+    if (c->comm_rank != root) rc = maus_matrix_reserve(c, rows, cols);
+    else if (a) rc = maus_set_matrix(c, a, rows, cols);
+    else { rc = (c->A && c->rows == rows && c->cols == cols) ? 0 : -1; if (rc) c->err = "no resident matrix of that shape on the root"; }
+    std::string local_err = (rc != 0) ? c->err : std::string();
+    if (ensure_comm_buf(c, 64)) return -1;
+    int* d_status = (int*)c->comm_buf;
+    int h_status = (c->comm_rank == root) ? rc : 0;
+    HIPCHK(c, hipMemcpyAsync(d_status, &h_status, sizeof(int), hipMemcpyHostToDevice, c->st));
+    NCCLCHK(c, rccl()->Broadcast(d_status, d_status, sizeof(int), ncclChar, root, (ncclComm_t)c->comm, c->st));
+    HIPCHK(c, hipMemcpyAsync(&h_status, d_status, sizeof(int), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (h_status != 0) {
+        if (c->comm_rank == root) FAIL(c, "maus_comm_set_matrix: upload failed on the root: " + local_err);
+        FAIL(c, "maus_comm_set_matrix: the root's upload of the matrix failed");
+    }
+    if (rc != 0) FAIL(c, "maus_comm_set_matrix: no device memory for the matrix on this rank: " + local_err);   // (the peers' broadcast below then fails too: RCCL's own error)
+    NCCLCHK(c, rccl()->Broadcast(c->A, c->A, bytes, ncclChar, root, (ncclComm_t)c->comm, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     return 0;
 }

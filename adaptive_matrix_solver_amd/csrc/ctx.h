@@ -95,6 +95,7 @@ struct maus_ctx {
     void* pin = nullptr; size_t pin_bytes = 0;           // pinned host staging buffer (maus_stage_h2d / _d2h, maus_pop_put / _get)
     hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_failed = false;
     char* pin_small = nullptr; size_t pin_small_off = 0;   // pinned ring for small asynchronous uploads (maus_h2d)
+    hipEvent_t pin_small_ev[2] = {nullptr, nullptr}; long pin_small_lap = 0; bool pin_small_mid = false;   // one event per half of the ring (maus_h2d)
     // measurement
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool prof_on = false;
@@ -118,6 +119,7 @@ extern thread_local std::string g_err;
         (ctx)->err = buf_; return -1; } } while (0)
 
 
+int maus_matrix_reserve(maus_ctx* c, int rows, int cols);     // capi.hip: device room for the problem matrix
 int ensure_scalars(maus_ctx* c, int count);
 int ensure_scratch(maus_ctx* c, size_t bytes);
 int check_slots(maus_ctx* c, const int* slots, int count);

@@ -442,6 +442,16 @@ static void herm_free(maus_ctx* c) {
     c->hqn = 0;
 }
 
+// The reflector store (n x n) and what else the decomposition keeps between its stages: callers that only wanted the
+// tridiagonal matrix (eigenvalues for the reporting prologue, singular values) hand it back at once -- 1 GiB at n = 8192 that
+// would otherwise stay resident until the next maus_set_matrix.
+int maus_herm_release(maus_ctx* c) {
+    if (!c) return -1;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    herm_free(c);
+    return 0;
+}
+
 int maus_herm_tridiag(maus_ctx* c, double* d_out, double* e_out) {
     if (!c->A || c->rows != c->cols) FAIL(c, "maus_herm_tridiag: square matrix required (maus_set_matrix)");
     if (!d_out || (!e_out && c->rows > 1)) FAIL(c, "maus_herm_tridiag: null output");

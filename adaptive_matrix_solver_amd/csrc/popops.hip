@@ -144,7 +144,7 @@ svd_resid_kernel(const c128* __restrict__ Yv, const c128* __restrict__ Uv, long 
 
 // nrm = ||src|| ; dst = src * (1 / (nrm > 1e-10 ? nrm : 1))     (AMS:234-235, 241-242)
 __global__ void __launch_bounds__(VT)
-norm_scale_kernel(const c128* __restrict__ S, c128* __restrict__ D, long ld, const int* __restrict__ slots, int n,
+norm_scale_kernel(const c128* S, c128* D, long ld, const int* __restrict__ slots, int n,      // S == D is a legitimate call (in place): no __restrict__ on them
                   double* __restrict__ norm_out, int stride_out, int off_out)
 {
     __shared__ double sbuf[VT / 64];

@@ -33,21 +33,37 @@ _MAGIC = b"MAUSRCCL1"
 
 
 def _token() -> bytes:
-    """What tells this job's id server from anything else that may listen near MASTER_PORT."""
-    return (os.environ.get("TORCHELASTIC_RUN_ID", "") + ":" + os.environ.get("MASTER_PORT", "") + ":" +
+    """What tells this job's id server from anything else that may listen near MASTER_PORT.  MAUS_JOB_SECRET -- a random string
+    the launcher exports to every rank (bench.py's self-launch does) -- when there is one; otherwise the launcher's run id."""
+    sec = os.environ.get("MAUS_JOB_SECRET", "")
+    return (sec + "|" + os.environ.get("TORCHELASTIC_RUN_ID", "") + ":" + os.environ.get("MASTER_PORT", "") + ":" +
             os.environ.get("WORLD_SIZE", "")).encode()
+
+
+def _recv_exact(conn, n: int) -> bytes:
+    buf = b""
+    while len(buf) < n:
+        chunk = conn.recv(n - len(buf))
+        if not chunk:
+            break
+        buf += chunk
+    return buf
 
 
 def _exchange_unique_id(rank: int, world: int, make_id, timeout: float = 300.0) -> bytes:
     """Rank 0 creates the RCCL unique id and serves it to the other ranks of this node over TCP.  The port is the first
-    free one above MASTER_PORT (the launcher's own store listens ON MASTER_PORT); clients probe the same range and check a
-    magic + job token, so a foreign listener is skipped rather than believed."""
+    free one above MASTER_PORT (the launcher's own store listens ON MASTER_PORT); clients probe the same range.  Hello =
+    magic + rank + token length + token, read in full; the reply echoes the client's rank and a digest of the token before the
+    id, so neither side believes a foreign peer that merely knows the magic."""
+    import hashlib
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     base = int(os.environ.get("MASTER_PORT", "29500"))
     ports = [base + 1 + k for k in range(32)]
     tok = _token()
+    proof = hashlib.sha256(b"reply" + tok).digest()[:16]
     if world == 1:
         return make_id()
+    head = len(_MAGIC) + 8
     if rank == 0:
         uid = make_id()
         srv = None
@@ -70,13 +86,13 @@ def _exchange_unique_id(rank: int, world: int, make_id, timeout: float = 300.0) 
                 with conn:
                     conn.settimeout(10.0)
                     try:
-                        hello = conn.recv(len(_MAGIC) + 8 + 256)
-                        if not hello.startswith(_MAGIC):
+                        hello = _recv_exact(conn, head)
+                        if len(hello) != head or not hello.startswith(_MAGIC):
                             continue
-                        r, ln = struct.unpack("<ii", hello[len(_MAGIC):len(_MAGIC) + 8])
-                        if hello[len(_MAGIC) + 8:len(_MAGIC) + 8 + ln] != tok or not (0 < r < world):
+                        r, ln = struct.unpack("<ii", hello[len(_MAGIC):])
+                        if not (0 <= ln <= 4096) or _recv_exact(conn, ln) != tok or not (0 < r < world):
                             continue
-                        conn.sendall(_MAGIC + uid)
+                        conn.sendall(_MAGIC + struct.pack("<i", r) + proof + uid)
                         served.add(r)
                     except OSError:
                         continue
@@ -85,20 +101,17 @@ def _exchange_unique_id(rank: int, world: int, make_id, timeout: float = 300.0) 
         return uid
     deadline = time.time() + timeout
     hello = _MAGIC + struct.pack("<ii", rank, len(tok)) + tok
+    want = len(_MAGIC) + 4 + len(proof) + 128
     while time.time() < deadline:
         for p in ports:
             try:
                 with socket.create_connection((addr, p), timeout=2.0) as s:
                     s.settimeout(5.0)
                     s.sendall(hello)
-                    buf = b""
-                    while len(buf) < len(_MAGIC) + 128:
-                        chunk = s.recv(len(_MAGIC) + 128 - len(buf))
-                        if not chunk:
-                            break
-                        buf += chunk
-                    if len(buf) == len(_MAGIC) + 128 and buf.startswith(_MAGIC):
-                        return buf[len(_MAGIC):]
+                    buf = _recv_exact(s, want)
+                    if (len(buf) == want and buf.startswith(_MAGIC) and struct.unpack("<i", buf[len(_MAGIC):len(_MAGIC) + 4])[0] == rank
+                            and buf[len(_MAGIC) + 4:len(_MAGIC) + 4 + len(proof)] == proof):
+                        return buf[-128:]
             except OSError:
                 continue
         time.sleep(0.2)
@@ -122,6 +135,7 @@ class PopulationComm:
             raise ValueError(f"PopulationComm: unknown transport {transport!r}")
         self.transport = transport
         self.on_device = transport == "rccl"     # candidate rows travel device to device; one rank per GPU is guaranteed
+        self.in_root_call = False
         self.collectives = 0
         self.bytes_gathered = 0
         self.seconds = 0.0                       # host wall time inside collectives (bench: per-rank report)
@@ -222,10 +236,13 @@ class PopulationComm:
         so no rank is left waiting inside a collective that the root never enters."""
         status = None
         if self.rank == root:
+            self.in_root_call = True            # (engine.bind_matrix: no collective from inside work the others do not take part in)
             try:
                 status = ("ok", fn())
             except Exception as e:                                  # noqa: BLE001 -- the point is that nothing escapes un-broadcast
                 status = ("err", f"{type(e).__name__}: {e}")
+            finally:
+                self.in_root_call = False
         status = self.bcast_object(status, root)
         if status[0] != "ok":
             raise RootFailure(f"rank {root} failed in work it does for all ranks: {status[1]}")

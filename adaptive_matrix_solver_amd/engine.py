@@ -272,10 +272,23 @@ class DeviceEngine:
 
     # ---- matrix / rhs binding -----------------------------------------------------------
     def bind_matrix(self, A):
-        if A is self._bound:
+        """The problem matrix on the device.  Sharded runs on RCCL: rank 0 alone stages it from the host, the others receive it
+        device to device -- one collective, entered by every rank: a matrix that rank 0 bound on its own inside
+        work it does for all (start-up diagnostics, comm.root_call) is broadcast from its device copy at the next bind."""
+        comm = self.comm
+        collective = comm is not None and comm.on_device and comm.world > 1 and not comm.in_root_call
+        solo = getattr(self, "_bound_solo", False)
+        if A is self._bound and not (collective and solo):
             return
         shape_changed = (self.ctx.rows, self.ctx.cols) != tuple(A.shape)
-        self.ctx.set_matrix(A)
+        if collective:
+            self.ctx.comm_set_matrix(A, comm.rank, 0, resident_on_root=(comm.rank == 0 and solo and A is self._bound))
+            comm.collectives += 1
+            comm.bytes_gathered += int(A.nbytes)
+            self._bound_solo = False
+        else:
+            self.ctx.set_matrix(A)
+            self._bound_solo = comm is not None and comm.on_device and comm.world > 1
         self._bound = A
         if shape_changed:
             self._free = []
@@ -801,9 +814,18 @@ class DeviceEngine:
         # second 270 GB allocation in the next one, for a workspace the step never touched)
 
         i = 0
+        self._pre_resid = {}
         while i < len(cands):
             run = cands[i:]
             slots = [c._slot for c in run]
+            # Sharded run, direct solver, stream-independent host side ('mt19937' / 'none'): this rank's share of the WHOLE step --
+            # Rayleigh quotient, shifted solve, relaxed update, residual -- before anything is exchanged, then one 64-byte record
+            # per candidate.  Accepted if no candidate of the run takes an exceptional branch (the common case by far);
+            # otherwise undone and the phase-by-phase path below takes the run.
+            if (self.comm is not None and pert != PERT_UNIFORM and pref == DIRECT
+                    and self._share_step(run, A, is_eig, base_psi, pert, words, n)):
+                i += len(run)
+                continue
             if is_eig:
                 num, den = self.d_rayleigh(run)
                 vnorm = np.sqrt(den.real)
@@ -944,6 +966,64 @@ class DeviceEngine:
                         cc._restore_device()
                 i += 1
 
+    def _share_step(self, run, A, is_eig, base_psi, pert, words, n) -> bool:
+        """one record per candidate and step.  Every rank runs AMS:264-286 + 295-301 for the candidates it owns,
+        speculatively (attempt 0 succeeds, no E2 / E4 event), and the owners' results travel in ONE all-gather of
+        [num.re, num.im, den.re, den.im, status, norm, residual, finite] (64 bytes).  Every rank then takes the same decision
+        from the same table: accept the run -- bookkeeping as in the phase-by-phase path, two collectives per loop body
+        with the row exchange -- or, on any exceptional branch, restore the vectors from the device-side snapshot and
+        return False."""
+        if any(c.problem_matrix is not A for c in run):             # SURVEY F9: residuals against another matrix object
+            return False
+        mine = self._mine(run)
+        loc = np.zeros((len(mine), 8))
+        ahead = _AsyncStreamAdvance(words * len(run)) if len(run) >= 8 else None
+        rng_start = np.random.get_state()
+        own_slots = [run[k]._slot for k in mine]
+        if mine:
+            num = den = np.zeros(len(mine), dtype=np.complex128)
+            lam = np.zeros(len(mine), dtype=np.complex128)
+            if is_eig:
+                num, den = self.ctx.matvec_rayleigh(own_slots)
+                for q in range(len(mine)):                              # AMS:264-268, the scalar arithmetic of the other path
+                    lam[q] = complex(0.0, 0.0) if np.abs(den[q]) < 1e-12 else num[q] / den[q]
+            stuck = np.array([run[k].stuck_counter for k in mine])
+            psi0 = np.array([(base_psi * (10 ** (0 / 2.0)) * (10 ** (sc / 3.0))).real for sc in stuck])   # AMS:44
+            pd = (rng_start, words, 0, np.asarray(mine, dtype=np.int32)) if pert == PERT_MT19937 else None
+            self.ctx.pop_copy(POP_U, POP_X, own_slots)                  # snapshot (POP_U is unused by eig / linear problems)
+            st = self.ctx.shifted_lu_solve(own_slots, lam, psi0, rhs_mode=0 if is_eig else 1, pert_mode=pert, pert_data=pd)
+            alpha = np.array([complex(run[k].alpha_local_step) for k in mine], dtype=np.complex128)
+            nrm = self.ctx.relax_normalise(own_slots, alpha, normalise=is_eig)
+            res, fin = self.ctx.residual(KIND_EIG if is_eig else KIND_LINEAR, own_slots, lam if is_eig else None)
+            loc = np.column_stack([num.real, num.imag, den.real, den.imag, st.astype(np.float64), nrm, res,
+                                   np.asarray(fin, dtype=np.float64)])
+        f = self._exchange(run, loc)
+        status, nrm = f[:, 4], f[:, 5]
+        bad = status != 0
+        if is_eig:
+            den = f[:, 2] + 1j * f[:, 3]
+            bad = bad | (np.sqrt(den.real) < 1e-10) | ~(nrm > 1e-10)    # E2 (AMS:259), E4 (AMS:283)
+        if bad.any():
+            if ahead is not None:
+                ahead.discard()
+            if mine:
+                self.ctx.pop_copy(POP_X, POP_U, own_slots)
+            return False
+        if is_eig:
+            num = f[:, 0] + 1j * f[:, 1]
+            for k, c in enumerate(run):
+                c.lambda_k = complex(0.0, 0.0) if np.abs(den[k]) < 1e-12 else num[k] / den[k]
+        for k, c in enumerate(run):
+            c.local_psi_retries_needed = 0                              # attempts == 0 (AMS:278)
+            c._invalidate()
+            c.stuck_counter = max(0, c.stuck_counter - 1)               # AMS:286
+            self._pre_resid[id(c)] = (f[k, 6], f[k, 7] != 0)
+        if ahead is not None:
+            ahead.apply()                                               # E3 of the whole run
+        else:
+            _advance_numpy_stream(words * len(run))
+        return True
+
     def _gmres_batch(self, run, shift, psi0, stuck, is_eig, pert=PERT_NONE, pert_data=None):
         """First GMRES attempt of a run (AMS:60-90 with tol->rtol).  Returns ok[]."""
         ok = np.zeros(len(run), dtype=bool)
@@ -1071,6 +1151,16 @@ class DeviceEngine:
         groups = {}
         for c in cands:
             groups.setdefault(id(c.problem_matrix), []).append(c)
+        pre = getattr(self, "_pre_resid", None) or {}
+        if pre and all(id(c) in pre for c in cands):
+            # the owners' residuals came with the step's record (_share_step): no second exchange
+            for k, c in enumerate(cands):
+                r, fin = pre[id(c)]
+                resv[k] = r
+                okv[k] = bool(fin) and (kind != ProblemType.EIGENVALUE or bool(np.isfinite(complex(c.lambda_k))))
+                c.residual_k = resv[k]
+            groups = {}
+        self._pre_resid = {}
         for _, grp in groups.items():
             self.bind_matrix(grp[0].problem_matrix)
             ix = np.fromiter((pos[id(c)] for c in grp), dtype=np.int64, count=len(grp))

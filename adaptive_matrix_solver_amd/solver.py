@@ -38,6 +38,8 @@ class ProblemType(Enum):                     # AMS:10-13
 # AMS:16-26
 GLOBAL_DEFAULT_PSI_EPSILON_BASE = np.complex128(1e-20)
 GLOBAL_DEFAULT_ALPHA_V_INITIAL = np.complex128(0.01)
+REFERENCE_LAZY_MIN = 512          # evolve(): general eigenvalues of larger matrices are computed when true_solution is first read
+_DEFERRED = object()
 GLOBAL_MAX_PSI_ATTEMPTS = 25
 GLOBAL_MAX_STUCK_FOR_RETIREMENT = 8
 GLOBAL_MIN_WEIGHT_TO_SURVIVE_PRUNE = 1e-10
@@ -565,9 +567,14 @@ class MAUS_Solver:
                     # (44 s + 70 s at n = 8192, profiles/r02_c4_hermitian_8192_end_to_end.txt)
                     import scipy.linalg as sla
                     try:
+                        evals = None
                         if self.engine.use_device_eigh(matrix.shape[0]):
-                            evals, evecs = self.engine.device_eigh(matrix), None       # V stays on the device
-                        else:
+                            from ._cabi import MausHipError
+                            try:
+                                evals, evecs = self.engine.device_eigh(matrix), None   # V stays on the device
+                            except MausHipError as err:                                # no device memory for the work copies, ...
+                                print(f"(device eigendecomposition failed: {err}; scipy.linalg.eigh on the host instead)")
+                        if evals is None:
                             evals, evecs = sla.eigh(matrix)
                         amax, amin = float(np.abs(evals).max()), float(np.abs(evals).min())
                         with np.errstate(divide="ignore"):
@@ -889,6 +896,22 @@ class MAUS_Solver:
         return n
 
     # ---- AMS:551-608 ------------------------------------------------------------------------------
+    @property
+    def true_solution(self):
+        """AMS:553-570: the reference answer of evolve()'s closing comparison (None before evolve() / if it failed)."""
+        if self._true_solution is _DEFERRED:
+            import time
+            t0 = time.perf_counter()
+            self._true_solution = self._reference_solution()
+            if time.perf_counter() - t0 > 5.0:
+                print(f"(reference solution for the closing comparison: {time.perf_counter() - t0:.1f} s on the host; "
+                      f"evolve(reference_check=False) skips it)")
+        return self._true_solution
+
+    @true_solution.setter
+    def true_solution(self, value):
+        self._true_solution = value
+
     def _reference_solution(self):
         """The reference's reporting prologue (AMS:554-570): a reference answer to compare the final report with.  Linear
         systems above n = 512 on the device LU, Hermitian spectra and singular values from n = 1536 up through the device
@@ -903,10 +926,18 @@ class MAUS_Solver:
                 if self.problem_knowledge.get("is_hermitian", False) and self.engine.use_device_eigh(self.N_rows):
                     # Hermitian: the spectrum of the tridiagonal matrix the device reduces M to (csrc/herm.hip) instead of a
                     # general QR iteration on the host -- eigenvalues only (bisection on the device), real, in eigvals()'s sorted order
-                    self.engine.bind_matrix(self.M)
-                    d, e = self.engine.ctx.herm_tridiag()
                     from .engine import tridiagonal_eigenvalues
-                    return np.sort(tridiagonal_eigenvalues(self.engine.ctx, d, e)).astype(np.complex128)
+                    from ._cabi import MausHipError
+                    try:
+                        self.engine.bind_matrix(self.M)
+                        d, e = self.engine.ctx.herm_tridiag()
+                        try:
+                            return np.sort(tridiagonal_eigenvalues(self.engine.ctx, d, e)).astype(np.complex128)
+                        finally:
+                            if hasattr(self.engine.ctx, "herm_release"):
+                                self.engine.ctx.herm_release()            # eigenvalues only: no back-transformation follows
+                    except MausHipError as err:                           # e.g. no device memory for the n x n work copies
+                        print(f"(device reduction for the reference eigenvalues failed: {err}; SciPy on the host instead)")
                 vals = sla.eigvals(self.M)
                 vals.sort()
                 return vals
@@ -948,20 +979,22 @@ class MAUS_Solver:
 
     def evolve(self, max_iterations=100, *, reference_check=None):
         """AMS:551-608.  `reference_check` (default on, as in the reference): the "true solution" prologue (AMS:554-570)
-        and the closing comparison.  Linear systems above n = 512 are solved by the device LU; eigenvalues and singular
-        values come from SciPy on the host -- O(n^3) there (about a minute at n = 4096), reported when it takes more than
-        a few seconds; False skips it."""
+        and the closing comparison.  Linear systems above n = 512 are solved by the device LU, Hermitian spectra and singular
+        values come from the device tridiagonalisation; general eigenvalues above n = 512 -- SciPy on the host, about a minute
+        at n = 4096 -- are computed lazily, when `true_solution` is first read; False skips the whole prologue."""
         print(f"--- Starting MAUS Evolution for {max_iterations} iterations ({self.problem_type.name}) ---")
         self.true_solution = None
         if reference_check is None:
             reference_check = True
         if reference_check:
-            import time
-            t0 = time.perf_counter()
-            self.true_solution = self._reference_solution()
-            if time.perf_counter() - t0 > 5.0:
-                print(f"(reference solution for the closing comparison: {time.perf_counter() - t0:.1f} s on the host; "
-                      f"evolve(reference_check=False) skips it)")
+            if (self.problem_type == ProblemType.EIGENVALUE and self.N_rows == self.N_cols and self.N_rows > REFERENCE_LAZY_MIN
+                    and not (self.problem_knowledge.get("is_hermitian", False) and self.engine.use_device_eigh(self.N_rows))):
+                # General eigenvalues are the one reference answer that still costs O(n^3) on the host (about a minute at
+                # n = 4096): computed when `true_solution` is first read -- by the closing comparison below, which only
+                # happens if something converged, or by the caller -- instead of in front of the first iteration.
+                self._true_solution = _DEFERRED
+            else:
+                self.true_solution = self._reference_solution()
         for i in range(max_iterations):
             self.loop_body(i + 1)
             target_sols_disp = self.N_diag
@@ -998,7 +1031,7 @@ class MAUS_Solver:
                 print(f"  LinSolve {k+1}: X_norm1={np.linalg.norm(t[0], 1):.6e}, Res={res:.2e}")
             else:
                 print(f"  SVD {k+1}: σ={t[0]:.6e}, Res={res:.2e}")
-        if self.true_solution is not None and self.num_distinct_converged_solutions > 0 and sols:
+        if self.num_distinct_converged_solutions > 0 and sols and self.true_solution is not None:
             print("--- Comparison to NumPy ---")
             if self.problem_type == ProblemType.EIGENVALUE:
                 found = np.array(sorted([t[0] for t in sols if t[0] is not None], key=lambda z: (z.real, z.imag)))

@@ -103,6 +103,7 @@ def self_launch(args) -> int:
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MAUS_JOB_SECRET", os.urandom(16).hex())        # dist.py: the ranks' RCCL id exchange trusts nobody without it
     return subprocess.call(cmd, env=env)
 
 
@@ -122,10 +123,22 @@ OTHER = {
 }
 
 
-def _oracle_baseline(kind, A, b, n, budget_s, max_steps):
-    """cpu_baseline of a side configuration: the oracle's candidate_step on the same matrix, bounded."""
+def _oracle_baseline(kind, A, b, n, budget_s, max_steps, herm_sample_n=None):
+    """cpu_baseline of a side configuration: the oracle's candidate_step on the same matrix, bounded.  herm_sample_n: one
+    Hermitian candidate step is one eigh of the whole matrix (AMS:161: 73 s at n = 8192 on this host's quota of cores), so the
+    default bench line times it on the leading herm_sample_n x herm_sample_n block and scales by (n / herm_sample_n)^3 --
+    labelled as an extrapolation; `--config c4` alone times the real thing."""
     from oracle import maus_oracle as orc
     import scipy
+    if kind == "herm" and herm_sample_n is not None and herm_sample_n < n:
+        sub = np.ascontiguousarray(A[:herm_sample_n, :herm_sample_n])
+        r = _oracle_baseline(kind, sub, None, herm_sample_n, budget_s, 1)
+        scale = (n / float(herm_sample_n)) ** 3
+        r["value"] /= scale
+        r["kind"] = "port (extrapolated)"
+        r["sample"] = (f"EXTRAPOLATED: {r['sample']} -- on the leading {herm_sample_n} x {herm_sample_n} block, divided by (n / {herm_sample_n})^3 = {scale:.0f} "
+                       f"(one step = one O(n^3) eigh, AMS:161)")
+        return r
     try:
         from threadpoolctl import threadpool_info
         pools = threadpool_info()
@@ -309,8 +322,51 @@ def run_other_config(args):
     if kind == "lin":
         out["gmres"] = {"calls": gm["calls"], "candidate_solves": gm["cands"], "inner_iterations_mean": gm["inner"] / max(1, gm["cands"])}
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = _oracle_baseline(kind, A, b, n, args.cpu_budget, 64)
+        out["cpu_baseline"] = _oracle_baseline(kind, A, b, n, args.cpu_budget, 64, herm_sample_n=2048 if args.side else None)
     print(json.dumps(out))
+
+
+SIDE_ORDER = ("c2", "c3", "c5", "c4")
+
+
+def run_side_configs(args):
+    """Short runs of the other BASELINE.json configurations, one child process each (`bench.py --config cX --side`: its own
+    context, nothing shared with the headline run), condensed into one entry per configuration.  c5 runs the population the
+    reference itself would build (AMS:366: at least 3 min(rows, cols) = 6 144 candidates, not BASELINE's 512); c4 one GPU's
+    share (128) of its 1 024 candidates; c3's first loop body (twice as long as the later ones) is inside its timed region."""
+    res = {}
+    t_all = time.perf_counter()
+    for name in SIDE_ORDER:
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--side", "--cpu-budget", "4"]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            line = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not line:
+                res[name] = {"error": f"exit code {p.returncode}", "stderr_tail": p.stderr.decode(errors="replace")[-400:]}
+                continue
+            d = json.loads(line[-1])
+        except Exception as e:                                   # noqa: BLE001 -- a side run must not take the headline line down
+            res[name] = {"error": f"{type(e).__name__}: {e}"}
+            continue
+        r = d["roofline"]
+        ent = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+               "steps": d["steps"], "warmup": d["warmup"], "candidate_steps_timed": d["config"]["candidate_steps_timed"],
+               "per_step_ms": [x["ms"] for x in d["per_step"]], "per_step_active": [x["active"] for x in d["per_step"]],
+               "roofline": {"bound": r["bound"], "kernel": r["kernel"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
+                            "frac": r["frac"], "kernel_time_share": r.get("kernel_time_share")},
+               "step_frac_of_mfma_peak": d["step_frac_of_mfma_peak"], "kernel_ms_profiled_pass": d["kernel_ms_profiled_pass"],
+               "solver_build_s": d["config"]["solver_build_s"], "wall_s_of_this_side_run": round(time.perf_counter() - t0, 1)}
+        if "gmres" in d:
+            ent["gmres"] = d["gmres"]
+        if "cpu_baseline" in d:
+            cb = d["cpu_baseline"]
+            ent["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"]}
+        res[name] = ent
+    res["wall_s_total"] = round(time.perf_counter() - t_all, 1)
+    return res
 
 
 def main():
@@ -335,6 +391,10 @@ def main():
                     help="HIP-event bracketing of kernel launches in the timed region: every K>=256 zgemm launch (default), "
                          "every launch of every kernel (costs 3-5 %% of throughput), or none")
     ap.add_argument("--cpu-budget", type=float, default=40.0)
+    ap.add_argument("--no-side", action="store_true",
+                    help="default config only: skip the short runs of the other BASELINE.json configurations (c2, c3, c5, c4) that "
+                         "are folded into the JSON line as `side_configs` (N=1)")
+    ap.add_argument("--side", action="store_true", help="(internal) this process is one of those short runs: bounded CPU baseline")
     ap.add_argument("--skip-diagnosis", action="store_true",
                     help="profiling aid: construct the solver with the known start-up diagnostics of the metric's matrix "
                          "(dense, non-Hermitian, 'Stable') instead of running the condition estimator, whose ten "
@@ -640,6 +700,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, n, args.cpu_budget)
+        if world == 1 and not args.no_side and n == 4096 and P == 256:
+            # the headline context goes first: its LU workspace holds most of the device memory
+            del solver
+            ctx.close()
+            out["side_configs"] = run_side_configs(args)
         print(json.dumps(out))
     if comm is not None:
         comm.barrier()

@@ -209,6 +209,9 @@ int maus_herm_match(maus_ctx* ctx, const int* slots, int count, int32_t* idx_out
  *                            eigenvector matrix, as if set by maus_set_eigvecs.
  * The first row of V is real (Q e_1 = e_1), LAPACK's phase convention. */
 int maus_herm_tridiag(maus_ctx* ctx, double* d_out, double* e_out);
+/* Frees the reflector store / eigenvectors of T that maus_herm_tridiag(_eig) keep for maus_herm_backtransform: for callers that
+ * only wanted the tridiagonal matrix or its eigenvalues (AMS:559, 567 reporting prologue; singular values of the start-up diagnostics). */
+int maus_herm_release(maus_ctx* ctx);
 /* the context's eigenvector matrix back on the host (v_out[n][n] complex128, row-major; tests, users of evolve()'s report) */
 int maus_get_eigvecs(maus_ctx* ctx, double* v_c128_out, int n);
 int maus_herm_backtransform(maus_ctx* ctx, const double* z_real, int col_major);
@@ -264,6 +267,9 @@ int maus_jacobi_check(maus_ctx* ctx, int count, const double* shift_c128, const 
  *   maus_comm_bcast          host buffer from `root` to all (start-up diagnostics, eigenvalues: computed by rank 0 only).
  *   maus_comm_bcast_eigvecs  the eigenvector matrix of the Hermitian shortcut (AMS:161; maus_set_eigvecs on `root` only),
  *                            device to device.
+ *   maus_comm_set_matrix     maus_set_matrix for a sharded run (A replicated): `root` uploads `a` from the host, the
+ *                            other ranks (a may be NULL there) receive it device to device; the root's failure is
+ *                            everybody's.  Replaces N staged host copies of AMS:343's matrix by one.
  *   maus_comm_stats          collectives issued, payload bytes, host wall ms inside them (reset != 0 zeroes them). */
 #define MAUS_COMM_ID_BYTES 128
 int maus_device_count(void);
@@ -275,6 +281,7 @@ int maus_comm_allgather_records(maus_ctx* ctx, const void* send, size_t bytes_pe
 int maus_comm_allgather_rows(maus_ctx* ctx, int which, const int* slots, const int* counts, int len);
 int maus_comm_bcast(maus_ctx* ctx, void* host_buf, size_t bytes, int root);
 int maus_comm_bcast_eigvecs(maus_ctx* ctx, int n, int root);
+int maus_comm_set_matrix(maus_ctx* ctx, const double* a, int rows, int cols, int root);
 int maus_comm_stats(maus_ctx* ctx, long* calls_out, double* bytes_out, double* ms_out, int reset);
 
 /* ---- plain batched GEMM on the context's stream (tests, Gram blocks) ----- */

@@ -30,22 +30,25 @@ EXTRA = {"eig16_p5": dict(kind="eig", build=("ginibre", 16, 16, 1.0), P=5, iters
          "herm16_p3": dict(kind="eig", build=("hermitian", 16, 16), P=3, iters=3, seed=5, tol=1e-8)}
 
 
-def _run(name, iters, comm):
+def _run(name, iters, comm, per_body=None, **kw):
     sys.path[:0] = [ROOT, os.path.join(HERE, "golden"), HERE]
     import scenarios
     import snapshot
     scenarios.TRAJECTORIES.update(EXTRA)
     from test_host_logic import make_solver, rows_of
-    solver, spec = make_solver(name, comm=comm)
+    solver, spec = make_solver(name, comm=comm, **kw)
     out = []
     for it in range(iters):
+        c0 = comm.collectives if comm is not None else 0
         solver.loop_body(it + 1)
+        if per_body is not None:
+            per_body.append((comm.collectives if comm is not None else 0) - c0)
         d = snapshot.digest_rows(rows_of(solver.candidates, spec["kind"]))
         out.append({"digest": d, "rng": snapshot.rng_digest(), "n": len(solver.candidates)})
     return out, (comm.collectives if comm is not None else 0)
 
 
-def _worker(rank, world, port, name, iters, outdir):
+def _worker(rank, world, port, name, iters, outdir, kw=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     import torch.distributed as dist
@@ -60,18 +63,19 @@ def _worker(rank, world, port, name, iters, outdir):
     comm.owners = lambda n: (asked.append(int(n)), owners(n))[1]
     real_eigh = sla.eigh
     sla.eigh = lambda *a, **k: (eigh_calls.__setitem__(0, eigh_calls[0] + 1), real_eigh(*a, **k))[1]
-    out, ncoll = _run(name, iters, comm)
+    per_body = []
+    out, ncoll = _run(name, iters, comm, per_body, **(kw or {}))
     with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
         json.dump({"out": out, "collectives": ncoll, "asked": asked, "eigh_calls": eigh_calls[0],
-                   "stats": comm.stats()}, f)
+                   "stats": comm.stats(), "per_body": per_body}, f)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _spawn(world, name, iters):
+def _spawn(world, name, iters, kw=None):
     import torch.multiprocessing as mp
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), name, iters, d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), name, iters, d, kw), nprocs=world, join=True)
         return [json.load(open(os.path.join(d, f"rank{r}.json"))) for r in range(world)]
 
 
@@ -102,6 +106,23 @@ def test_three_and_eight_ranks_equal_single_process(world, name, iters):
     if name.startswith("herm16"):
         # one eigh per matrix, on rank 0 only (the reference: one per candidate step, AMS:161)
         assert [g["eigh_calls"] for g in got] == [1] + [0] * (world - 1)
+
+
+@pytest.mark.parametrize("world,name,iters", [(2, "eig16", 8), (3, "eig64", 5), (3, "lin24", 6), (8, "eig16_p5", 4)])
+def test_one_record_exchange_per_step(world, name, iters):
+    """SURVEY 8e / VERDICT r03 item 7: with a stream-independent host side (pert_mode 'none' here; 'mt19937' on the device) a
+    sharded direct-solver step is this rank's share of the whole step, ONE all-gather of a 64-byte record per candidate, and the
+    row exchange: two collectives per loop body where the phase-by-phase path needs five -- with the bookkeeping, the vectors
+    and both RNG streams of the single-process run."""
+    kw = dict(pert_mode="none", gmres_compat="rtol")
+    ref, _ = _run(name, iters, None, **kw)
+    got = _spawn(world, name, iters, kw)
+    for r in range(world):
+        assert got[r]["out"] == ref, f"rank {r} of {world} diverged from the single-process run"
+        assert got[r]["per_body"] == got[0]["per_body"]
+    pb = got[0]["per_body"]
+    assert min(pb) == 2, pb                    # a loop body without an exceptional branch: record + rows
+    assert sum(1 for x in pb if x == 2) >= len(pb) // 2, pb
 
 
 def _failing_worker(rank, world, port, where, outdir):

@@ -79,5 +79,6 @@ def test_population_comm_over_rccl_world_size_one():
     assert r.returncode == 0, r.stderr[-3000:]
     rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["equal"], "the run through RCCL differs from the single-process run"
-    assert min(rec["collectives"][:3]) >= 4 * 4 and min(rec["bytes"]) > 0
+    # (r04: a direct-solver step is one record exchange + one row exchange, tests/test_dist_gloo.py::test_one_record_exchange_per_step)
+    assert min(rec["collectives"][:3]) >= 2 * 4 and min(rec["bytes"]) > 0
     assert not rec["torch_imported"], "the sharded product path must not need torch"

@@ -52,7 +52,7 @@ def test_configs3_loop_body_converges_every_candidate(herm8192):
         assert abs(np.linalg.norm(v) - 1.0) <= 1e-12
         assert isinstance(c.lambda_k, (float, np.floating)) or np.imag(c.lambda_k) == 0.0          # eigh's eigenvalues are real
         r = np.linalg.norm(A @ v - c.lambda_k * v)
-        assert r <= 200 * N * EPS * anorm and abs(r - c.residual_k) <= 1e-9 * max(r, 1e-12)
+        assert r <= 200 * N * EPS * anorm and abs(r - c.residual_k) <= 20 * EPS * anorm       # both are rounding noise of an exact eigenpair
     assert max(c.residual_k for c in cands) <= 200 * N * EPS * anorm
     assert s.engine.tridiag_solver == "device"
     # the rest of the loop body: the distinct converged set (one entry per distinct eigenpair) and the spawn of AMS:528-549
