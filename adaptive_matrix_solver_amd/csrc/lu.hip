@@ -531,26 +531,26 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
 // Base panel spread over W workgroups per matrix (small batches: with one workgroup per matrix a batch of 32 occupies 32
 // of the 256 CUs and the panel phase is bound by one CU's memory pipeline per matrix).  Workgroup w owns the logical rows
 // [w*RPT*PT, (w+1)*RPT*PT) of the panel and keeps its whole 16-column slice in registers (read once, written once); the
-// pivot search and the exchange of the pivot row go through a small per-matrix area in global memory:
-//   per column a:  every workgroup publishes its best row (|re|+|im|, logical index, physical row, the 16 entries) and,
-//                  if it owns logical row a, that row too; arrives on a monotone counter; waits for all W arrivals; reads
-//                  the W candidates, picks the winner by the izamax rule (max value, lowest logical index) and reads its
-//                  row.  One rendezvous per column.
-// Published words are written and read with agent-scope relaxed atomics (sc1: they bypass the per-CU L1 and are
-// written through the XCD's L2), drained with s_waitcnt before the arrival is counted (MI355X_MICROARCH.md, valid
-// hand-off forms); buffers alternate with the column parity, which is enough because nobody can be two rendezvous ahead.
-// Every wait is bounded: after ~2 s without progress a workgroup raises the abort word, everybody leaves, and the
+// pivot search and the exchange of the pivot row go through a small per-matrix area in global memory, ONE hand-off per column
+// (round 4; rounds 2-3 needed three dependent trips through L2: publish + drain, arrive on a counter and wait, read the
+// candidates):
+//   per column a:  every workgroup publishes its best row -- |re|+|im|, logical index, physical row, the 16 entries -- and, if
+//                  it owns logical row a, that row too, as 8-byte GRANULES {tag = (panel, column), 32 bits of payload}, each written by
+//                  one agent-scope atomic store; every workgroup polls all granules of the column (one per thread) until each
+//                  carries the column's tag.  A granule validates itself -- data and tag arrive in one store -- so there is no
+//                  flag, no counter and nothing to drain (MI355X_MICROARCH.md: data-tagged granules, handoff-1to1).  The winner
+//                  is then picked out of LDS by the izamax rule (max value, lowest logical index).
+// Granule buffers alternate with the column parity: nobody can be two columns ahead, because publishing column a + 2 takes the
+// candidates of column a + 1 from everybody, and those are published only after their owners have read column a.
+// Every wait is bounded: after ~2 s without progress a thread raises the abort word, everybody leaves, and the
 // matrix reports info = INT_MIN (internal error) instead of hanging the device.  The launcher only uses this kernel
 // when all G*W workgroups are co-resident by construction (one launch in flight, G*W <= number of CUs).
 // ---------------------------------------------------------------------------------------
 constexpr int MW_MAXW = 8;
-struct MwSync {                         // one per matrix; zeroed before every panel launch
-    unsigned long long cnt;             // arrivals (monotone: column a is complete at (a+1)*W)
+constexpr int MW_GRAN = 4 + 4 * NBP;    // payload words of one record: value lo / hi, physical row, logical row, 16 complex entries
+struct MwSync {                         // one per matrix; zeroed at the start of every factorisation (tags are unique inside one)
     unsigned long long abort_;          // non-zero: a wait timed out
-    unsigned long long meta[2][MW_MAXW][2];   // [parity][w]: value bits, (logical row << 32 | physical row)
-    unsigned long long aphys[2];              // physical row of logical row a
-    double row[2][MW_MAXW][2 * NBP];          // candidate rows
-    double arow[2][2 * NBP];                  // row a
+    unsigned long long gran[2][MW_MAXW + 1][MW_GRAN];    // [parity][workgroup w; slot MW_MAXW = logical row a][word]: tag << 32 | payload
 };
 
 __device__ __forceinline__ void mw_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -560,7 +560,7 @@ template <int RPT>
 __global__ void __launch_bounds__(PT)
 lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long strideH, int j0, int m, int W,
                    int* __restrict__ ipiv_g, int* __restrict__ perm_g, int npad, int* __restrict__ info_g, MwSync* __restrict__ sync_g,
-                   unsigned long long timeout_ticks, int force_abort)
+                   unsigned long long timeout_ticks, int force_abort, unsigned tag_base)
 {
     // blockIdx.x = matrix, blockIdx.y = row chunk: workgroups are dealt round-robin over the 8 XCDs by linear id, so with a
     // batch that is a multiple of 8 the W workgroups of one matrix share an XCD -- and its L2 -- (speed only)
@@ -652,33 +652,54 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         }
         lds_barrier();
         PCLK(9);
-        // ---- publish (wave 0: candidate, wave 1: row a), drain, arrive ----
-        if (wave == 0) {
-            if (lane < 2 * NBP) mw_store((unsigned long long*)&sy->row[par][w][lane], __double_as_longlong(((const double*)s_row)[lane]));
-            if (lane == 32) mw_store(&sy->meta[par][w][0], (unsigned long long)__double_as_longlong(best));
-            if (lane == 33) mw_store(&sy->meta[par][w][1], ((unsigned long long)(unsigned)bidx << 32) | (unsigned)(bidx == INT_MAX ? 0 : s_phys[0]));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (wave == 1 && own_a) {
-            if (lane < 2 * NBP) mw_store((unsigned long long*)&sy->arow[par][lane], __double_as_longlong(((const double*)s_arow)[lane]));
-            if (lane == 32) mw_store(&sy->aphys[par], (unsigned long long)(unsigned)s_phys[1]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- publish: one granule per thread, no drain, no flag ----
+        const unsigned tag = tag_base | (unsigned)(a + 1);             // unique within a factorisation: (panel + 1) << 5 | column + 1
+        const unsigned long long tagw = (unsigned long long)tag << 32;
+        // test hook (MAUS_PANEL_MW_FORCE_ABORT): the last workgroup of matrix 0 publishes nothing for column 3, so its
+        // siblings -- and then itself, one column later -- run into the time-out exactly as if it had never become resident
+        const bool mute = force_abort && g == 0 && w == W - 1 && a == 3;
+        if (tid < MW_GRAN && !mute) {
+            unsigned pay;
+            if (tid == 0) pay = (unsigned)(__double_as_longlong(best) & 0xffffffffll);
+            else if (tid == 1) pay = (unsigned)((unsigned long long)__double_as_longlong(best) >> 32);
+            else if (tid == 2) pay = (bidx == INT_MAX) ? 0u : (unsigned)s_phys[0];
+            else if (tid == 3) pay = (unsigned)bidx;
+            else pay = ((const unsigned*)s_row)[tid - 4];
+            mw_store(&sy->gran[par][w][tid], tagw | pay);
         }
-        lds_barrier();
+        if (own_a && tid >= 64 && tid < 64 + MW_GRAN && !mute) {
+            const int i = tid - 64;
+            const unsigned pay = (i == 2) ? (unsigned)s_phys[1] : (i >= 4 ? ((const unsigned*)s_arow)[i - 4] : 0u);
+            mw_store(&sy->gran[par][MW_MAXW][i], tagw | pay);
+        }
+        lds_barrier();                  // s_row / s_arow / s_phys have been read: the gather below overwrites them
         PCLK(10);
-        if (tid == 0) {
-            // test hook (MAUS_PANEL_MW_FORCE_ABORT): the last workgroup of matrix 0 skips its arrival at column 3, so its
-            // siblings -- and then itself -- run into the time-out exactly as if it had never become resident
-            if (!(force_abort && g == 0 && w == W - 1 && a == 3))
-            __hip_atomic_fetch_add(&sy->cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long target = (unsigned long long)(a + 1) * W;
+        // ---- gather: every granule of the column, one per thread, polled until it carries the column's tag.  (Polling the W
+        //      metas first and then only the winner's row -- a quarter of the pollers -- was slower, 22.0 vs 19.9 ms of panel
+        //      time per 32-solve call: the second, dependent trip costs more than the extra pollers.) ----
+        {
+            const int total = (W + 1) * MW_GRAN;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
-            int spins = 0;
-            while (mw_load(&sy->cnt) < target) {
-                if (mw_load(&sy->abort_)) { s_abort = 1; break; }
-                if ((++spins & 1023) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
-                    mw_store(&sy->abort_, 1ull); s_abort = 1; break;
+            for (int e = tid; e < total; e += PT) {
+                const int q = e / MW_GRAN, i = e - q * MW_GRAN;
+                const unsigned long long* gp_ = &sy->gran[par][q < W ? q : MW_MAXW][i];
+                unsigned long long v;
+                int spins = 0;
+                bool got = true;
+                while ((unsigned)(v = mw_load(gp_), v >> 32) != tag) {
+                    if ((++spins & 255) == 0) {
+                        if (mw_load(&sy->abort_)) { got = false; break; }
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) { mw_store(&sy->abort_, 1ull); got = false; break; }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                __builtin_amdgcn_s_sleep(1);
+                if (!got) { s_abort = 1; break; }
+                const unsigned pay = (unsigned)(v & 0xffffffffull);
+                if (q < W) {
+                    if (i < 4) ((unsigned*)s_meta)[q * 4 + i] = pay;            // [value lo, value hi, physical row, logical row]
+                    else ((unsigned*)s_all)[q * (4 * NBP) + (i - 4)] = pay;
+                } else if (i == 2) s_phys[1] = (int)pay;
+                else if (i >= 4) ((unsigned*)s_arow)[i - 4] = pay;
             }
         }
         lds_barrier();
@@ -686,22 +707,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         aborted = (s_abort != 0);
       }
       if (!aborted) {
-        const int par = a & 1;
         const bool own_a = (w == 0);
-        // ---- one read phase: the W metas, the W candidate rows and row a; the winner (izamax rule: max value, lowest
-        //      logical index) is then picked out of LDS ----
-        {
-            const int nmeta = 2 * W, nrow = 2 * NBP * W, narow = 2 * NBP;
-            for (int e = tid; e < nmeta + nrow + narow + 1; e += PT) {
-                if (e < nmeta) s_meta[e >> 1][e & 1] = mw_load(&sy->meta[par][e >> 1][e & 1]);
-                else if (e < nmeta + nrow) { const int q = (e - nmeta) / (2 * NBP), i = (e - nmeta) % (2 * NBP);
-                                             s_all[q][i] = __longlong_as_double((long long)mw_load((const unsigned long long*)&sy->row[par][q][i])); }
-                else if (e < nmeta + nrow + narow) { const int i = e - nmeta - nrow;
-                                                     ((double*)s_arow)[i] = __longlong_as_double((long long)mw_load((const unsigned long long*)&sy->arow[par][i])); }
-                else s_phys[1] = (int)(unsigned)mw_load(&sy->aphys[par]);
-            }
-        }
-        lds_barrier();
         PCLK(12);
         double gv = -1.0; int gp = INT_MAX, gw = 0, gphys = 0;
         for (int q = 0; q < W; ++q) {
@@ -1080,10 +1086,10 @@ static void lu_panel(const LuWs& w, int j0) {
         const int wmax = std::min(p2floor(std::max(1, ncu / std::max(1, w.G))), MW_MAXW);
         const int W = std::max(wmin, std::min(wmax, p2floor(m / 256)));
         if (W >= 2 && W <= wmax) {
-            (void)hipMemsetAsync(w.mw_sync, 0, sizeof(MwSync) * (size_t)w.G, w.st);
             const int rpt1 = (m + W * PT - 1) / (W * PT);
-            if (rpt1 <= 1) hipLaunchKernelGGL((lu_panel_mw_kernel<1>), dim3(w.G, W), block, 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, j0, m, W, w.ipiv, w.perm, w.npad, w.info, (MwSync*)w.mw_sync, w.mw_timeout, w.mw_force_abort);
-            else hipLaunchKernelGGL((lu_panel_mw_kernel<2>), dim3(w.G, W), block, 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, j0, m, W, w.ipiv, w.perm, w.npad, w.info, (MwSync*)w.mw_sync, w.mw_timeout, w.mw_force_abort);
+            const unsigned tag_base = (unsigned)(j0 / NBP + 1) << 5;
+            if (rpt1 <= 1) hipLaunchKernelGGL((lu_panel_mw_kernel<1>), dim3(w.G, W), block, 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, j0, m, W, w.ipiv, w.perm, w.npad, w.info, (MwSync*)w.mw_sync, w.mw_timeout, w.mw_force_abort, tag_base);
+            else hipLaunchKernelGGL((lu_panel_mw_kernel<2>), dim3(w.G, W), block, 0, w.st, w.H, w.U, (long)LU_TW, w.strideH, j0, m, W, w.ipiv, w.perm, w.npad, w.info, (MwSync*)w.mw_sync, w.mw_timeout, w.mw_force_abort, tag_base);
             prof(w, KC_PANEL, 1, 8.0 * m * NBP * NBP / 2 * w.G, 16.0 * m * NBP * 2 * w.G);
             return;
         }
@@ -1126,6 +1132,7 @@ size_t maus_lu_mw_sync_bytes() { return 64; }
 void maus_lu_factor(const LuWs& w, int nbo) {
     const int ncols = (int)w.ldh;                 // npad + 32
     w.dinv_upto = 0;
+    if (w.mw_sync) (void)hipMemsetAsync(w.mw_sync, 0, maus_lu_mw_sync_bytes() * (size_t)w.G, w.st);      // abort words and tags of the multi-workgroup panel
     hipLaunchKernelGGL(init_perm_kernel, dim3((w.npad + 255) / 256, w.G), dim3(256), 0, w.st, w.perm, w.npad);
     for (int J = 0; J < w.npad; J += nbo) {
         int wd = (w.npad - J < nbo) ? (w.npad - J) : nbo;

@@ -36,9 +36,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (AMD spec)
 HBM_PEAK_GBS = 8000.0
-PMC_ZGEMM = "r03_zgemm_pmc_traffic.json"
-PMC_KERNELS = "r03_pmc_traffic_per_kernel.json"
-PMC_MFMA = "r03_pmc_mfma_lds_per_kernel.json"
+PMC_ZGEMM = "r04_zgemm_pmc_traffic.json"
+PMC_KERNELS = "r04_pmc_traffic_per_kernel.json"
+PMC_MFMA = "r04_pmc_mfma_lds_per_kernel.json"
 
 
 def cpu_baseline(A, n, budget_s=25.0):
@@ -629,7 +629,8 @@ def main():
         pmc_mfma = None
         try:
             with open(os.path.join(ROOT, "profiles", PMC_MFMA)) as f:
-                pm = json.load(f)["zgemm3m_dma_kernel<2, 3, 2, 2, true>"]
+                pj = json.load(f)
+                pm = pj[[k for k in pj if k.startswith("zgemm3m_dma_kernel<2, 3, 2, 2, true")][0]]
             pmc_mfma = {"kernel": "zgemm3m_dma_kernel<2, 3, 2, 2, true> (64x64 tiles: the K = 512 outer updates with M, N >= 1536)",
                         "MfmaUtil": round(pm["mfma_util"], 4), "effective_clock_GHz": round(pm["effective_clock_GHz"], 3),
                         "mfma_tflops_executed": round(pm["mfma_tflops_executed"], 2),

@@ -18,12 +18,14 @@ import json
 import os
 import sys
 
-LU_ZGEMM = re.compile(r"zgemm(3m_dma)?_kernel<[^>]*, true>")
+LU_ZGEMM = re.compile(r"zgemm_kernel<[^>]*, true>|zgemm3m_dma_kernel<\d+, \d+, \d+, \d+, true,")       # TILED = true: the LU's instantiations
 trace_path, dirs = sys.argv[1], sys.argv[2:]
 trace = [tuple(int(x) for x in line.split()) for line in open(trace_path) if line.strip()]
 
 
 def klass(name):
+    if "lu_diaginv" in name:            # round 4: the inverted diagonal blocks belong to the triangular solves
+        return "trsm"
     for key in ("zgemm", "lu_panel", "laswp", "trsm", "build_h", "backsolve", "mt_jump", "init_perm"):
         if key in name:
             return key
