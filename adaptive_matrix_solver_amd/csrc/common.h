@@ -58,6 +58,33 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Pivot search inside one wave (LAPACK izamax: largest value, lowest index among equals): on return every lane holds the wave's
+// (best, bidx).  Values are >= 0 or -1 ("no row"), never NaN.  Two reductions on the DPP network -- the maximum of the values,
+// then the minimum index among the lanes that hold it -- instead of six butterfly rounds through ds_bpermute (three LDS-crossbar
+// trips per round, each waited for): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror make the 16 lanes of a DPP row
+// agree (max and min are idempotent, so a mirror is as good as a butterfly), four v_readlane join the rows.
+__device__ __forceinline__ void wave_argmax(double& best, int& bidx) {
+    double v = best;
+#define MAUS_DPP_F64(CTRL) __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false), \
+                                            __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false))
+    v = fmax(v, MAUS_DPP_F64(0xB1));
+    v = fmax(v, MAUS_DPP_F64(0x4E));
+    v = fmax(v, MAUS_DPP_F64(0x141));
+    v = fmax(v, MAUS_DPP_F64(0x140));
+#undef MAUS_DPP_F64
+    auto lane_f64 = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
+    const double m = fmax(fmax(lane_f64(0), lane_f64(16)), fmax(lane_f64(32), lane_f64(48)));
+    unsigned c = (best == m) ? (unsigned)bidx : 0xffffffffu;             // bidx >= 0 (INT_MAX = none)
+    c = min(c, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)c, 0xB1, 0xf, 0xf, false));
+    c = min(c, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)c, 0x4E, 0xf, 0xf, false));
+    c = min(c, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)c, 0x141, 0xf, 0xf, false));
+    c = min(c, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)c, 0x140, 0xf, 0xf, false));
+    const unsigned i0 = (unsigned)__builtin_amdgcn_readlane((int)c, 0), i1 = (unsigned)__builtin_amdgcn_readlane((int)c, 16);
+    const unsigned i2 = (unsigned)__builtin_amdgcn_readlane((int)c, 32), i3 = (unsigned)__builtin_amdgcn_readlane((int)c, 48);
+    best = m;
+    bidx = (int)min(min(i0, i1), min(i2, i3));
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e. for every global
 // load and STORE the wave has in flight; where only LDS data changes hands between the phases that is a needless
 // HBM round trip per barrier.

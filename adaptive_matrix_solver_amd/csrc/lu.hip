@@ -218,6 +218,8 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
     __shared__ int s_prow[NBP];                   // physical rows of the pivots chosen so far
     __shared__ int s_pphys, s_aphys;
     __shared__ int s_info;
+    __shared__ c128 s_rinv;                       // 1 / pivot (1 for an exact zero pivot), by the pivot row's owner
+    __shared__ int s_zero;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_info = 0;
@@ -291,12 +293,7 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
                     if (v > best) { best = v; bidx = r; }
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                double ov = __shfl_xor(best, o, 64);
-                int oi = __shfl_xor(bidx, o, 64);
-                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-            }
+            wave_argmax(best, bidx);
             if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
             lds_barrier();
             best = s_val[0]; bidx = s_idx[0];
@@ -306,46 +303,58 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
                 if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
             }
             const int p = (bidx == INT_MAX) ? a : bidx;   // all-NaN column: no interchange (input flagged non-finite)
-            // ---- publish pivot row / displaced row of the register sub-block and their physical rows ----
+            // ---- publish pivot row / displaced row of the register sub-block and their physical rows.  Logical row p lives in
+            //      thread p % PT as its row p / PT: ONE vector compare finds the owner and the row index is wave-uniform, so
+            //      the unrolled `k == kp` tests are scalar branches (round 3 compared every row of every thread with p and with
+            //      a, twice per column: ~100 of the ~450 instructions of a column step).  The owner also inverts the pivot --
+            //      three fp64 divisions that every thread used to repeat ----
+            constexpr int LOG_PT = 9;
+            static_assert(PT == 1 << LOG_PT, "owner of a logical row");
+            const int kp = p >> LOG_PT, tp = p & (PT - 1);
+            if (tid == tp) {
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = tid + k * PT;
-                if (r == p) {
+                for (int k = 0; k < RPT; ++k) {
+                    if (k == kp) {
 #pragma unroll
-                    for (int cc = 0; cc < PWL; ++cc) s_piv[cc] = R[k][cc];
-                    s_pphys = pr.get(k);
+                        for (int cc = 0; cc < PWL; ++cc) s_piv[cc] = R[k][cc];
+                        s_pphys = pr.get(k);
+                        const c128 pv = R[k][c];
+                        const bool zp = (pv.x == 0.0 && pv.y == 0.0);
+                        s_rinv = zp ? cmake(1.0, 0.0) : crecip(pv);
+                        s_zero = zp ? 1 : 0;
+                    }
                 }
-                if (r == a && p != a) {
+            }
+            if (tid == a && p != a) {                      // logical row a < 16: row 0 of thread a
 #pragma unroll
-                    for (int cc = 0; cc < PWL; ++cc) s_old[cc] = R[k][cc];
-                    s_aphys = pr.get(k);
-                }
+                for (int cc = 0; cc < PWL; ++cc) s_old[cc] = R[0][cc];
+                s_aphys = pr.get(0);
             }
             if (tid == 0) ipiv[a] = j0 + p;
             lds_barrier();
             // the interchange: two threads exchange the register rows AND the physical rows they stand for
+            if (p != a) {
+                if (tid == a) {
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = tid + k * PT;
-                if (p != a) {
-                    if (r == a) {
+                    for (int cc = 0; cc < PWL; ++cc) R[0][cc] = s_piv[cc];
+                    pr.set(0, s_pphys);
+                }
+                if (tid == tp) {
 #pragma unroll
-                        for (int cc = 0; cc < PWL; ++cc) R[k][cc] = s_piv[cc];
-                        pr.set(k, s_pphys);
-                    } else if (r == p) {
+                    for (int k = 0; k < RPT; ++k) {
+                        if (k == kp) {
 #pragma unroll
-                        for (int cc = 0; cc < PWL; ++cc) R[k][cc] = s_old[cc];
-                        pr.set(k, s_aphys);
+                            for (int cc = 0; cc < PWL; ++cc) R[k][cc] = s_old[cc];
+                            pr.set(k, s_aphys);
+                        }
                     }
                 }
             }
             if (tid == 0) s_prow[a] = s_pphys;
             // row a of U inside this sub-block (columns >= a); the columns of later sub-blocks follow in their (b')
             if (tid < PWL && tid >= c) Um[(long)a * ld + c0 + tid] = s_piv[tid];
-            const c128 pv = s_piv[c];
-            const bool zero_piv = (pv.x == 0.0 && pv.y == 0.0);
-            if (zero_piv && tid == 0 && s_info == 0) s_info = j0 + a + 1;   // LAPACK info (1-based)
-            const c128 rinv = zero_piv ? cmake(1.0, 0.0) : crecip(pv);
+            if (s_zero && tid == 0 && s_info == 0) s_info = j0 + a + 1;   // LAPACK info (1-based)
+            const c128 rinv = s_rinv;
             c128 prow[PWL];
 #pragma unroll
             for (int cc = 0; cc < PWL; ++cc) prow[cc] = s_piv[cc];
@@ -409,6 +418,9 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
     __shared__ c128 s_row[NBP];          // the pivot row
     __shared__ c128 s_arow[NBP];         // logical row a (displaced by the interchange)
     __shared__ int s_phys[2];            // physical rows of the pivot row / of logical row a
+    __shared__ c128 s_rinv;              // 1 / pivot (1 for an exact zero pivot), by the pivot row's owner
+    __shared__ int s_zero;
+    static_assert((NT & (NT - 1)) == 0, "owner of a logical row");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     c128 R[RPT][NBP];
@@ -440,12 +452,7 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
                 if (v > best) { best = v; bidx = r; }
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            double ov = __shfl_xor(best, o, 64);
-            int oi = __shfl_xor(bidx, o, 64);
-            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-        }
+        wave_argmax(best, bidx);
         if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
         lds_barrier();
         PCLK(5);
@@ -456,45 +463,52 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
             if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
         }
         const int p = (bidx == INT_MAX) ? a : bidx;   // all-NaN column: no interchange (input flagged non-finite)
-        // ---- publish the pivot row and the row it displaces ----
+        // ---- publish the pivot row and the row it displaces: by their owners (thread p % NT, row p / NT: see
+        //      lu_panel_ip_kernel); the pivot row's owner inverts the pivot for everybody ----
+        const int kp = p / NT, tp = p % NT;                  // NT is a power of two
+        if (tid == tp) {
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int r = tid + k * NT;
-            if (r == p) {
+            for (int k = 0; k < RPT; ++k) {
+                if (k == kp) {
 #pragma unroll
-                for (int c = 0; c < NBP; ++c) s_row[c] = R[k][c];
-                s_phys[0] = pr[k];
+                    for (int c = 0; c < NBP; ++c) s_row[c] = R[k][c];
+                    s_phys[0] = pr[k];
+                    const c128 pv = R[k][a];
+                    const bool zp = (pv.x == 0.0 && pv.y == 0.0);
+                    s_rinv = zp ? cmake(1.0, 0.0) : crecip(pv);
+                    s_zero = zp ? 1 : 0;
+                }
             }
-            if (r == a && p != a) {
+        }
+        if (tid == a && p != a) {                            // logical row a < 16 <= NT: row 0 of thread a
 #pragma unroll
-                for (int c = 0; c < NBP; ++c) s_arow[c] = R[k][c];
-                s_phys[1] = pr[k];
-            }
+            for (int c = 0; c < NBP; ++c) s_arow[c] = R[0][c];
+            s_phys[1] = pr[0];
         }
         lds_barrier();
         PCLK(6);
         // ---- the interchange: the owners of logical rows a and p exchange register rows and physical rows ----
         if (p != a) {
+            if (tid == a) {
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = tid + k * NT;
-                if (r == a) {
+                for (int c = 0; c < NBP; ++c) R[0][c] = s_row[c];
+                pr[0] = s_phys[0];
+            }
+            if (tid == tp) {
 #pragma unroll
-                    for (int c = 0; c < NBP; ++c) R[k][c] = s_row[c];
-                    pr[k] = s_phys[0];
-                } else if (r == p) {
+                for (int k = 0; k < RPT; ++k) {
+                    if (k == kp) {
 #pragma unroll
-                    for (int c = 0; c < NBP; ++c) R[k][c] = s_arow[c];
-                    pr[k] = s_phys[1];
+                        for (int c = 0; c < NBP; ++c) R[k][c] = s_arow[c];
+                        pr[k] = s_phys[1];
+                    }
                 }
             }
         }
-        const c128 pv = s_row[a];
-        const bool zero_piv = (pv.x == 0.0 && pv.y == 0.0);
-        if (zero_piv && my_info == 0) my_info = j0 + a + 1;              // LAPACK info (1-based)
+        if (s_zero && my_info == 0) my_info = j0 + a + 1;                // LAPACK info (1-based)
         if (tid == 0) ipiv[a] = j0 + p;
         if (tid < NBP && tid >= a) Um[(long)a * ld + tid] = s_row[tid];   // row a of U inside the panel
-        const c128 rinv = zero_piv ? cmake(1.0, 0.0) : crecip(pv);
+        const c128 rinv = s_rinv;
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int r = tid + k * NT;
@@ -579,6 +593,8 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
     __shared__ unsigned long long s_meta[MW_MAXW][2];
     __shared__ double s_all[MW_MAXW][2 * NBP];       // every workgroup's candidate row
     __shared__ int s_abort;
+    __shared__ c128 s_rinv;              // 1 / pivot (1 for an exact zero pivot)
+    __shared__ int s_zero;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rbase = w * RPT * PT;
@@ -621,12 +637,7 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
                 if (v > best) { best = v; bidx = r; }
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            double ov = __shfl_xor(best, o, 64);
-            int oi = __shfl_xor(bidx, o, 64);
-            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-        }
+        wave_argmax(best, bidx);
         if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
         lds_barrier();
         best = s_val[0]; bidx = s_idx[0];
@@ -636,19 +647,22 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
             if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
         }
         const bool own_a = (w == 0);                 // logical rows 0..15 belong to the first workgroup
+        // (owners: local row q = r - rbase lives in thread q % PT as its row q / PT, see lu_panel_ip_kernel)
+        if (bidx != INT_MAX && tid == ((bidx - rbase) & (PT - 1))) {
+            const int kb = (bidx - rbase) >> 9;
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int r = rbase + tid + k * PT;
-            if (r == bidx) {
+            for (int k = 0; k < RPT; ++k) {
+                if (k == kb) {
 #pragma unroll
-                for (int c = 0; c < NBP; ++c) s_row[c] = R[k][c];
-                s_phys[0] = pr[k];
+                    for (int c = 0; c < NBP; ++c) s_row[c] = R[k][c];
+                    s_phys[0] = pr[k];
+                }
             }
-            if (r == a) {
+        }
+        if (own_a && tid == a) {
 #pragma unroll
-                for (int c = 0; c < NBP; ++c) s_arow[c] = R[k][c];
-                s_phys[1] = pr[k];
-            }
+            for (int c = 0; c < NBP; ++c) s_arow[c] = R[0][c];
+            s_phys[1] = pr[0];
         }
         lds_barrier();
         PCLK(9);
@@ -719,32 +733,41 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         const int p = none ? a : gp;
         if (tid < 2 * NBP) ((double*)s_row)[tid] = none ? ((const double*)s_arow)[tid] : s_all[gw][tid];
         if (tid == 0) s_phys[0] = none ? s_phys[1] : gphys;
+        if (tid == 64) {                                 // the pivot's inverse, once (three fp64 divisions every thread used to repeat)
+            const double* src = none ? (const double*)s_arow : s_all[gw];
+            const c128 pv = cmake(src[2 * a], src[2 * a + 1]);
+            const bool zp = (pv.x == 0.0 && pv.y == 0.0);
+            s_rinv = zp ? cmake(1.0, 0.0) : crecip(pv);
+            s_zero = zp ? 1 : 0;
+        }
         lds_barrier();
         PCLK(13);
         // ---- the interchange: the owners of logical rows a and p exchange register rows and physical rows ----
         if (p != a) {
+            if (own_a && tid == a) {
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = rbase + tid + k * PT;
-                if (r == a) {
+                for (int c = 0; c < NBP; ++c) R[0][c] = s_row[c];
+                pr[0] = s_phys[0];
+            }
+            const int q = p - rbase;                     // the winner lives in this workgroup iff 0 <= q < RPT * PT
+            if (q >= 0 && q < RPT * PT && tid == (q & (PT - 1))) {
+                const int kq = q >> 9;
 #pragma unroll
-                    for (int c = 0; c < NBP; ++c) R[k][c] = s_row[c];
-                    pr[k] = s_phys[0];
-                } else if (r == p) {
+                for (int k = 0; k < RPT; ++k) {
+                    if (k == kq) {
 #pragma unroll
-                    for (int c = 0; c < NBP; ++c) R[k][c] = s_arow[c];
-                    pr[k] = s_phys[1];
+                        for (int c = 0; c < NBP; ++c) R[k][c] = s_arow[c];
+                        pr[k] = s_phys[1];
+                    }
                 }
             }
         }
-        const c128 pv = s_row[a];
-        const bool zero_piv = (pv.x == 0.0 && pv.y == 0.0);
-        if (zero_piv && my_info == 0) my_info = j0 + a + 1;              // LAPACK info (1-based)
+        if (s_zero && my_info == 0) my_info = j0 + a + 1;                // LAPACK info (1-based)
         if (own_a) {
             if (tid == 0) ipiv[a] = j0 + p;
             if (tid < NBP && tid >= a) Um[(long)a * ld + tid] = s_row[tid];       // row a of U inside the panel
         }
-        const c128 rinv = zero_piv ? cmake(1.0, 0.0) : crecip(pv);
+        const c128 rinv = s_rinv;
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int r = rbase + tid + k * PT;

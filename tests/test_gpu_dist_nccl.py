@@ -62,6 +62,20 @@ for n in names:
         comm.bcast_eigvecs(s.engine.ctx, None, 16)
         Vd = s.engine.ctx.get_eigvecs()
         assert np.linalg.norm(s.M @ Vd - Vd * ev[None, :]) < 1e-12 and np.abs(Vd[0].imag).max() == 0.0
+    if n == "eig64":
+        # maus_comm_set_matrix (r04): the root uploads, or broadcasts the copy its device already holds; the matvec that follows
+        # reads the broadcast matrix
+        ctx = s.engine.ctx
+        B = (np.random.default_rng(2).standard_normal((64, 64)) + 1j * np.random.default_rng(3).standard_normal((64, 64)))
+        ctx.comm_set_matrix(B, comm.rank, 0)
+        ctx.pop_reserve(4)
+        X = np.eye(4, 64, dtype=np.complex128)
+        ctx.pop_put(0, [0, 1, 2, 3], X)
+        num, den = ctx.matvec_rayleigh([0, 1, 2, 3])
+        assert np.allclose(num, np.diag(B)[:4]) and np.allclose(den, 1.0)
+        ctx.comm_set_matrix(B, comm.rank, 0, resident_on_root=True)
+        num2, _ = ctx.matvec_rayleigh([0, 1, 2, 3])
+        assert np.array_equal(num, num2)
     comm.barrier()
     stats.append(comm.stats())
     lib_stats = s.engine.ctx.comm_stats()
