@@ -570,7 +570,8 @@ class DeviceEngine:
         for c in cands:
             c.b_vector = b                                  # AMS:146
             c.prev_residual = c.residual_k                  # AMS:147
-            c._push()                                       # make sure device rows are current
+            if not c._dev_valid:
+                c._push()                                   # make sure device rows are current
         self.steps_executed += len(cands)
 
         todo = list(cands)
@@ -1144,13 +1145,19 @@ class DeviceEngine:
         S = SolutionCandidate.State
         kind = cands[0].problem_type
         n = len(cands)
-        pos = {id(c): k for k, c in enumerate(cands)}
         resv = np.empty(n, dtype=np.float64)
         okv = np.empty(n, dtype=bool)
-        # residual against the construction-time matrix of each candidate
-        groups = {}
-        for c in cands:
-            groups.setdefault(id(c.problem_matrix), []).append(c)
+        # residual against the construction-time matrix of each candidate: one group -- the whole list, no index
+        # bookkeeping -- unless somebody mixed candidates of different matrix objects
+        mats = {id(c.problem_matrix) for c in cands}
+        if len(mats) == 1:
+            pos = None
+            groups = {0: cands}
+        else:
+            pos = {id(c): k for k, c in enumerate(cands)}
+            groups = {}
+            for c in cands:
+                groups.setdefault(id(c.problem_matrix), []).append(c)
         pre = getattr(self, "_pre_resid", None) or {}
         if pre and all(id(c) in pre for c in cands):
             # the owners' residuals came with the step's record (_share_step): no second exchange
@@ -1163,7 +1170,7 @@ class DeviceEngine:
         self._pre_resid = {}
         for _, grp in groups.items():
             self.bind_matrix(grp[0].problem_matrix)
-            ix = np.fromiter((pos[id(c)] for c in grp), dtype=np.int64, count=len(grp))
+            ix = slice(None) if pos is None else np.fromiter((pos[id(c)] for c in grp), dtype=np.int64, count=len(grp))
             if kind == ProblemType.EIGENVALUE:
                 lam = np.array([complex(c.lambda_k) for c in grp], dtype=np.complex128)
                 res, fin = self.d_residual(KIND_EIG, grp, lam)
@@ -1177,8 +1184,8 @@ class DeviceEngine:
                 fin = np.asarray(fin, dtype=bool) & np.isfinite(sig)
             resv[ix] = res
             okv[ix] = fin
-            for k, c in enumerate(grp):
-                c.residual_k = res[k]
+            for c, r in zip(grp, res):                   # (iterating the array yields the np.float64 scalars res[k] would)
+                c.residual_k = r
         self.bind_matrix(A)
         thr = strat.get("current_convergence_threshold", CONVERGENCE_RESIDUAL_TOL)
         self._stage_history(cands)
@@ -1199,16 +1206,17 @@ class DeviceEngine:
             new_alpha = np.where(clamped, np.where(m1, 1.0, 1e-6), raw)
             conv = (resv < thr) & okv                                            # AMS:318-331
         code = (m1 * 1 + m2 * 2 + m3 * 3).tolist()
+        c128 = np.complex128
+        alpha_c = list(new_alpha.astype(c128))          # the same values as np.complex128 scalars (the type an unclamped alpha keeps)
         new_alpha = new_alpha.tolist()
         clamped = clamped.tolist()
-        c128 = np.complex128
         conv = conv.tolist()
         CONV, STUCK, RETIRED = S.CONVERGED, S.STUCK, S.RETIRED
         for k, c in enumerate(cands):
             c._record_history()                                          # AMS:303-304
             cd = code[k]
             if cd:
-                c.alpha_local_step = new_alpha[k] if (clamped[k] or type(alpha_old[k]) is not c128) else c128(new_alpha[k])
+                c.alpha_local_step = new_alpha[k] if (clamped[k] or type(alpha_old[k]) is not c128) else alpha_c[k]
                 st = c.state
                 if cd == 1:
                     if st is not CONV:
