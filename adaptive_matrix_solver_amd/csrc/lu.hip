@@ -181,6 +181,30 @@ __device__ unsigned long long g_panel_clk[16];
 // 51.5 vs 53.6 ms per 181-solve sweep, 34.2 vs 30.0 at 32); 1024 threads per workgroup (69 vs 54 ms); one barrier per
 // column with per-wave candidate rows published before it, DPP maximum and pivot rows kept in LDS (67 vs 54 ms: the
 // column step is bound by its instruction count, not by its barriers).
+// The inverse of the unit lower triangular 16 x 16 diagonal block of the panel a workgroup has just factored (round 4: the
+// triangular solves multiply by it, trsm_mfma_kernel).  sL = the block (only its strictly lower part is read); thread c < 16
+// substitutes column c of the inverse -- x_c = 1, x_i = -sum_{k<i} L[i][k] x_k below it -- and stores its strictly lower part
+// where nothing else lives: below the diagonal of the same block of the logical-order U array (Um = its row 0, column 0).
+// Inside the panel kernels this costs one wave a few microseconds at the very end; as a kernel of its own (the first version)
+// it was 256 launches of ~7 us per factorisation.
+__device__ __forceinline__ void panel_store_diaginv(const c128 (*sL)[17], c128* __restrict__ Um, long ld, int tid)
+{
+    if (tid < 16) {
+        c128 x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            c128 sacc = cmake(i == tid ? 1.0 : 0.0, 0.0);
+            if (i > tid) {
+#pragma unroll
+                for (int k = 0; k < i; ++k) cfms(sacc, sL[i][k], x[k]);
+            }
+            x[i] = sacc;
+        }
+#pragma unroll
+        for (int i = 1; i < 16; ++i) if (i > tid) Um[(long)i * ld + tid] = x[i];
+    }
+}
+
 // physical rows of a thread's logical rows (k is a compile-time constant at every use: the loops are unrolled).  LDS_BACKED: the
 // 16-rows-per-thread variant (m > 4096) keeps them in LDS, [k][thread] as 16-bit entries (npad <= 8192) -- in registers they
 // were what the kernel spilled
@@ -388,6 +412,12 @@ lu_panel_ip_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
 #pragma unroll
     for (int k = 0; k < RPT; ++k) { const int r = tid + k * PT; if (r < m) perm[r] = pr.get(k); }
     if (tid == 0 && s_info != 0 && info_g[blockIdx.x] == 0) info_g[blockIdx.x] = s_info;
+    // the diagonal block's inverse: its rows are the 16 pivot rows, stored sub-block by sub-block (the barrier behind the last
+    // store has made them visible to the whole workgroup)
+    __shared__ c128 s_diag[16][17];
+    if (tid < 256) { const int r = tid >> 4, c = tid & 15; s_diag[r][c] = Hm[(long)s_prow[r] * ld + c]; }
+    __syncthreads();
+    panel_store_diaginv(s_diag, Um, ld, tid);
 }
 
 #if MAUS_NBP == 16
@@ -538,6 +568,14 @@ lu_panel_rs_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         }
     }
     if (tid == 0 && my_info != 0 && info_g[g] == 0) info_g[g] = my_info;
+    // the diagonal block's inverse: logical row i < 16 is row 0 of thread i
+    __shared__ c128 s_diag[16][17];
+    if (tid < 16) {
+#pragma unroll
+        for (int c = 0; c < NBP; ++c) s_diag[tid][c] = R[0][c];
+    }
+    __syncthreads();
+    panel_store_diaginv(s_diag, Um, ld, tid);
     PCLK_SYNC(4);
 }
 
@@ -799,6 +837,15 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
         }
     }
     if (tid == 0 && w == 0 && my_info != 0 && info_g[g] == 0) info_g[g] = my_info;
+    if (w == 0) {                        // the diagonal block's inverse: logical row i < 16 is row 0 of thread i of the first workgroup
+        __shared__ c128 s_diag[16][17];
+        if (tid < 16) {
+#pragma unroll
+            for (int c = 0; c < NBP; ++c) s_diag[tid][c] = R[0][c];
+        }
+        __syncthreads();
+        panel_store_diaginv(s_diag, Um, ld, tid);
+    }
     PCLK(15);
 }
 
@@ -818,38 +865,11 @@ lu_panel_mw_kernel(c128* __restrict__ Hg, c128* __restrict__ Ug, long ld, long s
 //     straight from the factored panel columns through perm (L2-resident: every strip of a matrix reads the same blocks);
 //   * Dinv_bi = inverse of the unit lower triangular 16 x 16 diagonal block (LAPACK's own large-n zgetrf reaches its U12
 //     through ztrsm, which libraries implement with inverted diagonal blocks as well).  |l| <= 1 under partial pivoting.  Its
-//     strictly lower part is computed once per block by lu_diaginv_kernel and kept where nothing else lives: below the
+//     strictly lower part is computed once per block at the end of the panel kernel that factored it (panel_store_diaginv)
+//     and kept where nothing else lives: below the
 //     diagonal of the same block of the logical-order U array.
 // All B tiles of a strip are requested before the first product (32 loads per lane in flight).
 // =======================================================================================
-__global__ void __launch_bounds__(64)
-lu_diaginv_kernel(const c128* __restrict__ Hg, c128* __restrict__ Ug, long strideH, const int* __restrict__ perm_g, int npad, int j)
-{
-    const int g = blockIdx.y, jb = j + 16 * blockIdx.x, lane = threadIdx.x;
-    __shared__ c128 sL[16][17];
-    const c128* H = Hg + (long)g * strideH + lu_tile_off(npad, jb);
-    c128* U = Ug + (long)g * strideH + lu_tile_off(npad, jb) + (long)jb * LU_TW;
-    const int* perm = perm_g + (long)g * npad + jb;
-#pragma unroll
-    for (int e = lane; e < 256; e += 64) { const int r = e >> 4, c = e & 15; sL[r][c] = H[(long)perm[r] * LU_TW + c]; }
-    __syncthreads();
-    if (lane < 16) {
-        // column `lane` of the inverse: x_c = 1, x_i = -sum_{k<i} L[i][k] x_k below it (x_k = 0 above)
-        c128 x[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            c128 s = cmake(i == lane ? 1.0 : 0.0, 0.0);
-            if (i > lane) {
-#pragma unroll
-                for (int k = 0; k < i; ++k) cfms(s, sL[i][k], x[k]);
-            }
-            x[i] = s;
-        }
-#pragma unroll
-        for (int i = 1; i < 16; ++i) if (i > lane) U[(long)i * LU_TW + lane] = x[i];
-    }
-}
-
 template <int NB>
 __global__ void __launch_bounds__(256, 2)
 trsm_mfma_kernel(const c128* __restrict__ Hg, c128* __restrict__ Ug, long strideH, const int* __restrict__ perm_g,
@@ -1063,12 +1083,6 @@ static void lu_trsm(const LuWs& w, int j, int k, int c_lo, int c_hi) {
     // up to 128 rows: one launch of the register-resident MFMA solve (trsm_mfma_kernel); beyond that two halves with the
     // zgemm update between them
     if (k <= 128) {
-        if (w.dinv_upto < j + k) {          // inverses of the diagonal blocks factored since the last solve (panels finish left to right)
-            prof(w, KC_TRSM, 0);
-            hipLaunchKernelGGL(lu_diaginv_kernel, dim3((j + k - w.dinv_upto) / 16, w.G), dim3(64), 0, w.st, w.H, w.U, w.strideH, w.perm, w.npad, w.dinv_upto);
-            prof(w, KC_TRSM, 1, 0, 0);
-            w.dinv_upto = j + k;
-        }
         prof(w, KC_TRSM, 0);
         dim3 grid(((c_hi - c_lo) / 16 + 3) / 4, w.G);
 #define TRSM_MFMA(NB) case NB: hipLaunchKernelGGL((trsm_mfma_kernel<NB>), grid, dim3(256), 0, w.st, w.H, w.U, w.strideH, w.perm, w.npad, j, c_lo, c_hi); break
@@ -1154,7 +1168,6 @@ size_t maus_lu_mw_sync_bytes() { return 64; }
 // Factor all G matrices in the workspace and carry the augmented column through (L y = P b).
 void maus_lu_factor(const LuWs& w, int nbo) {
     const int ncols = (int)w.ldh;                 // npad + 32
-    w.dinv_upto = 0;
     if (w.mw_sync) (void)hipMemsetAsync(w.mw_sync, 0, maus_lu_mw_sync_bytes() * (size_t)w.G, w.st);      // abort words and tags of the multi-workgroup panel
     hipLaunchKernelGGL(init_perm_kernel, dim3((w.npad + 255) / 256, w.G), dim3(256), 0, w.st, w.perm, w.npad);
     for (int J = 0; J < w.npad; J += nbo) {

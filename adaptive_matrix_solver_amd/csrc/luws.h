@@ -25,9 +25,6 @@ struct LuWs {
     // implicit pivoting: rows never move.  perm[g][i] = physical row of H that holds logical row i; the finished rows of
     // U (and the carried right-hand side) are written in LOGICAL order to the second array U (same ld / stride as H)
     c128* U; int* perm;
-    // columns [0, dinv_upto): the inverses of the 16 x 16 unit lower triangular diagonal blocks of L are in place (below the
-    // diagonal of the same blocks of U; lu.hip, trsm_mfma_kernel).  Driver state of one factorisation.
-    mutable int dinv_upto = 0;
     void* mw_sync = nullptr;     // per-matrix rendezvous area of the multi-workgroup panel; null unless this LU is alone on the device
     // multi-workgroup panel: how long a rendezvous may wait (100 MHz ticks) before the matrix is reported as
     // info = INT_MIN (the caller then repeats the batch with one workgroup per matrix), and the test hook that makes one
