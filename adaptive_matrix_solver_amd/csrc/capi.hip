@@ -237,7 +237,7 @@ int maus_ctx_destroy(maus_ctx* c) {
     for (auto e : c->pin_small_ev) if (e) (void)hipEventDestroy(e);
     for (auto ev : c->pin_ev) if (ev) (void)hipEventDestroy(ev);
     hist_free(c);
-    for (auto& kv : c->mt_taps) if (kv.second.first) (void)hipFree(kv.second.first);
+    for (auto& kv : c->mt_taps) if (kv.second.taps) (void)hipFree(kv.second.taps);
     for (auto& b : c->mt_bufs) { if (b.states) (void)hipFree(b.states); if (b.ints) (void)hipFree(b.ints); if (b.base) (void)hipFree(b.base); }
     for (auto& r : c->pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
@@ -739,20 +739,27 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
     if (mt_buf_reserve(c, sbi, ngen, pl.hs.size())) return -1;
     struct DevLevel { size_t off; int count; MausJumpPolys P; int src_off; bool multi; };
     std::vector<DevLevel> levels;
-    auto poly_taps = [&](uint64_t J, const int** taps_out, int* ntap16_out) -> int {     // tap list of x^J mod phi, cached on the device
+    auto poly_taps = [&](uint64_t J, MausJumpPolys& P, int v) -> int {     // tap list of x^J mod phi, cached on the device
         auto it = c->mt_taps.find(J);
         if (it == c->mt_taps.end()) {
             std::vector<uint64_t> poly(312);
             if (maus_mt_jump_poly(J, poly.data())) FAIL(c, "MT19937 jump polynomial failed");
+            const int split = maus_mt_tap_split(), ztap = maus_mt_zero_tap();
             std::vector<int> taps;
-            for (int i = 0; i < 19937; ++i) if ((poly[i >> 6] >> (i & 63)) & 1ull) taps.push_back(i);
-            while (taps.size() % 16) taps.push_back(maus_mt_zero_tap());
+            int nlo16 = 0;
+            for (int half = 0; half < 2; ++half) {
+                for (int i = half ? split : 0; i < (half ? 19937 : split); ++i)
+                    if ((poly[i >> 6] >> (i & 63)) & 1ull) taps.push_back(half ? i - split : i);
+                while (taps.size() % 16) taps.push_back(ztap);
+                if (!half) nlo16 = (int)(taps.size() / 16);
+            }
+            if (taps.empty()) taps.assign(16, ztap);
             int* dt = nullptr;
             HIPCHK(c, hipMalloc((void**)&dt, sizeof(int) * taps.size()));
             HIPCHK(c, hipMemcpy(dt, taps.data(), sizeof(int) * taps.size(), hipMemcpyHostToDevice));
-            it = c->mt_taps.emplace(J, std::make_pair(dt, (int)(taps.size() / 16))).first;
+            it = c->mt_taps.emplace(J, maus_ctx::MtTaps{dt, (int)(taps.size() / 16), nlo16}).first;
         }
-        *taps_out = it->second.first; *ntap16_out = it->second.second;
+        P.taps[v] = it->second.taps; P.ntap16[v] = it->second.ntap16; P.nlo16[v] = it->second.nlo16;
         return 0;
     };
     for (const MausMtPlan::Level& L : pl.levels) {
@@ -761,7 +768,7 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
         bool need[16] = {false};
         if (L.multi) for (int i = 0; i < L.count; ++i) need[pl.hs[L.off + L.count + i] & 15] = true;
         else need[1] = true;
-        for (int v = 1; v < 16; ++v) if (need[v] && poly_taps((uint64_t)v * L.J, &D.P.taps[v], &D.P.ntap16[v])) return -1;
+        for (int v = 1; v < 16; ++v) if (need[v] && poly_taps((uint64_t)v * L.J, D.P, v)) return -1;
         levels.push_back(D);
     }
     const std::vector<int>& hs = pl.hs;

@@ -19,6 +19,7 @@ int maus_lu_max_npad();
 size_t maus_lu_mw_sync_bytes();
 void maus_mt_copy_states(hipStream_t st, uint32_t* states, const uint32_t* base, int count);
 #include "mtjump.h"
+int maus_mt_tap_split();
 void maus_mt_jump(hipStream_t st, uint32_t* states, const int* sel, const int* mult, int nsel, const MausJumpPolys& P, int src_off);
 int maus_mt_zero_tap();
 void maus_build_h_mt(hipStream_t st, const c128* A, int n, int npad, long ldh, long strideH, c128* H, int G, int S, long E,
@@ -75,7 +76,8 @@ struct maus_ctx {
     // still read theirs
     struct MtBuf { uint32_t* states = nullptr; int* ints = nullptr; uint32_t* base = nullptr; int cap = 0; size_t int_cap = 0; };
     std::vector<MtBuf> mt_bufs;
-    std::map<uint64_t, std::pair<int*, int>> mt_taps;   // J -> (device tap list of x^J mod phi, #taps/16)
+    struct MtTaps { int* taps; int ntap16, nlo16; };
+    std::map<uint64_t, MtTaps> mt_taps;                 // J -> device tap list of x^J mod phi in the two-window form of mt_jump_kernel
     MausMtPlan mt_plan;                                 // host plan + staging image of the current sub-batch (mtplan.cpp)
     // optional sub-batch streams (MAUS_LU_STREAMS > 1): bandwidth-bound phases of one sub-batch beside the
     // MFMA-bound trailing updates of another

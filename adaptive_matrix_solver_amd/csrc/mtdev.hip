@@ -56,12 +56,19 @@ __device__ __forceinline__ void regen_block(const uint32_t* od, uint32_t* nw, in
 
 // states[g] <- g(F) states[g - src_off] for the generators listed in `sel` (src_off = 0: in place; the doubling tree over
 // the sub-stream index reads the state of another generator, mtplan.cpp).  g is given as the list of its set
-// coefficients (`taps`, padded to a multiple of 16 with ZTAP, which points at a zero region), so
-// out[j] = XOR_t x[taps[t] + j] over the generator's own next 19937+624 words: a GF(2) convolution.
-// The tap indices are wave-uniform (scalar loads); each iteration issues 16 independent LDS reads.
+// coefficients (`taps`), so out[j] = XOR_t x[taps[t] + j] over the generator's own next 19937+624 words: a GF(2)
+// convolution.  The tap indices are wave-uniform (scalar loads); each iteration issues 16 independent LDS reads.
+// The kernel is bound by LDS bandwidth (~10 000 taps x 624 words per jump), so what matters is how many waves a CU has in
+// flight: the stream is walked in TWO windows of 17 blocks (45 KB of LDS, three workgroups per CU) instead of one of 33
+// (85 KB, one per CU; rounds 2-4).  Window 0 = blocks 0..16 serves the taps below JSPLIT (tap + 623 stays inside it),
+// window 1 = blocks 16..32 the others, rebased by the host; either list is padded to a multiple of 16 with ZTAP, which
+// points at a zero region.
 constexpr int JT = 640;                                  // one output word per thread (624 used)
-constexpr int XS_WORDS = CONV_BLOCKS * MTN;              // 20592
+constexpr int JWIN = 17;                                 // blocks per window
+constexpr int JSPLIT = (JWIN - 1) * MTN;                 // first tap of the second window
+constexpr int XS_WORDS = JWIN * MTN;
 constexpr int ZTAP = XS_WORDS;                           // xs[ZTAP .. ZTAP+JT) == 0
+static_assert(JSPLIT + XS_WORDS >= CONVN, "two windows must cover the stream a jump needs");
 __global__ void __launch_bounds__(JT)
 mt_jump_kernel(uint32_t* states, const int* __restrict__ sel, const int* __restrict__ mult, MausJumpPolys P, int src_off)
 {
@@ -69,22 +76,33 @@ mt_jump_kernel(uint32_t* states, const int* __restrict__ sel, const int* __restr
     const int tid = threadIdx.x;
     const int v = mult ? mult[blockIdx.x] : 1;             // which polynomial of the launch: x^(v J)  (workgroup-uniform)
     const int* __restrict__ taps = P.taps[v];
-    const int ntap16 = P.ntap16[v];
+    const int nlo16 = P.nlo16[v], ntap16 = P.ntap16[v];
     uint32_t* S = states + (long)sel[blockIdx.x] * MTN;
     const uint32_t* Src = S - (long)src_off * MTN;
     for (int k = tid; k < MTN; k += JT) xs[k] = Src[k];
     xs[ZTAP + tid] = 0u;
     __syncthreads();
-    for (int b = 1; b < CONV_BLOCKS; ++b) regen_block(xs + (b - 1) * MTN, xs + b * MTN, tid, JT);
     const uint32_t* xt = xs + tid;
     uint32_t acc0 = 0u, acc1 = 0u, acc2 = 0u, acc3 = 0u;
-    for (int t = 0; t < ntap16; ++t) {
-        const int4* tp = reinterpret_cast<const int4*>(taps + 16 * t);
-        const int4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
-        acc0 ^= xt[a.x] ^ xt[a.y] ^ xt[a.z] ^ xt[a.w];
-        acc1 ^= xt[b.x] ^ xt[b.y] ^ xt[b.z] ^ xt[b.w];
-        acc2 ^= xt[c.x] ^ xt[c.y] ^ xt[c.z] ^ xt[c.w];
-        acc3 ^= xt[d.x] ^ xt[d.y] ^ xt[d.z] ^ xt[d.w];
+    int t = 0;
+    for (int win = 0; win < 2; ++win) {
+        for (int bk = 1; bk < JWIN; ++bk) regen_block(xs + (bk - 1) * MTN, xs + bk * MTN, tid, JT);
+        const int t_end = win ? ntap16 : nlo16;
+        for (; t < t_end; ++t) {
+            const int4* tp = reinterpret_cast<const int4*>(taps + 16 * t);
+            const int4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
+            acc0 ^= xt[a.x] ^ xt[a.y] ^ xt[a.z] ^ xt[a.w];
+            acc1 ^= xt[b.x] ^ xt[b.y] ^ xt[b.z] ^ xt[b.w];
+            acc2 ^= xt[c.x] ^ xt[c.y] ^ xt[c.z] ^ xt[c.w];
+            acc3 ^= xt[d.x] ^ xt[d.y] ^ xt[d.z] ^ xt[d.w];
+        }
+        if (win == 0) {                                     // block 16 becomes block 0 of the second window
+            __syncthreads();
+            const uint32_t carry = (tid < MTN) ? xs[JSPLIT + tid] : 0u;
+            __syncthreads();
+            if (tid < MTN) xs[tid] = carry;
+            __syncthreads();
+        }
     }
     if (tid < MTN) S[tid] = acc0 ^ acc1 ^ acc2 ^ acc3;
 }
@@ -284,6 +302,7 @@ void maus_mt_copy_states(hipStream_t st, uint32_t* states, const uint32_t* base,
     hipLaunchKernelGGL(mt_copy_state_kernel, dim3(count), dim3(256), 0, st, states, base, count);
 }
 int maus_mt_zero_tap() { return ZTAP; }
+int maus_mt_tap_split() { return JSPLIT; }
 void maus_mt_jump(hipStream_t st, uint32_t* states, const int* sel, const int* mult, int nsel, const MausJumpPolys& P, int src_off) {
     if (nsel > 0) hipLaunchKernelGGL(mt_jump_kernel, dim3(nsel), dim3(JT), 0, st, states, sel, mult, P, src_off);
 }

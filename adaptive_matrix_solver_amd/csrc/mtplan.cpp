@@ -23,10 +23,13 @@ int maus_mt_plan(const maus_mt_desc* d, int n, int first, int g, int s_override,
     if (d->pos < 0 || d->pos > 624) return fail("maus_mt_desc: bad position");
     if (d->words_per_candidate % two_n2 || d->lead_words % two_n2 || d->words_per_candidate < 2 * two_n2 || !d->ordinals)
         return fail("maus_mt_desc: words_per_candidate / lead_words must be multiples of 2*n*n");
-    // sub-streams per draw (one 4-wave workgroup each): a power of two (measured at 181 candidates: 8 -> 15.3 ms, 9 -> 18.5,
-    // 16 -> 16.5, 4 -> 21.9 per H build), enough of them to cover the chip a few times, each at least ~64 blocks long
+    // sub-streams per draw (one 4-wave workgroup each): a power of two, the smallest that gives the H build ~1000 workgroups
+    // (measured at 181 candidates, n = 4096: 8 -> 15.3 ms, 9 -> 18.5, 16 -> 16.5, 4 -> 21.9 per H build).  Not more: every
+    // further sub-stream costs a jump, i.e. as much LDS traffic as generating 3300 blocks -- at n = 1024 a whole draw -- and
+    // at 256 candidates of n = 1024 eight sub-streams instead of four cost 2048 more jumps (0.96 ms) for the same 1.7 ms of
+    // H build (round 4: 21.0 -> 20.1 ms per 256-solve call).  Each sub-stream at least ~64 blocks long.
     int S = 1;
-    while (2 * S <= 16 && 2 * S * std::max(1, g) <= 2048) S *= 2;
+    while (2 * S <= 16 && (long)S * std::max(1, g) < 1024) S *= 2;
     const uint64_t nn = (uint64_t)n * n;
     while (S > 1 && nn / S < 64 * 312) --S;
     if (s_override > 0) S = std::max(1, std::min(64, s_override));

@@ -1,0 +1,16 @@
+# round 4: configs[1]: jump kernel variants, sub-stream count
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04
+T=${1:-c2c}
+mkdir -p $O
+timeout -k 10 300 python -m pytest tests/test_gpu_mt19937.py -x -q > $O/${T}_tests.txt 2>&1; tail -3 $O/${T}_tests.txt
+for s in 0 4; do
+  echo "MAUS_MT_SUBSTREAMS=$s"
+  MAUS_MT_SUBSTREAMS=$s LU_N=1024 LU_BATCH_KERNELS=1 timeout -k 10 200 python tools/lu_batch_rates.py 32 256
+done > $O/${T}_rates.txt 2>&1; cat $O/${T}_rates.txt
+rm -rf $O/trace && mkdir -p $O/trace
+LU_N=1024 timeout -k 10 300 rocprofv3 --kernel-trace -d $O/trace -o t -- python3 tools/lu_batch_rates.py 256 > $O/${T}_trace.out 2>&1
+DB=$(find $O/trace -name "*.db" | head -1)
+python3 tools/trace_db.py $DB mt_jump > $O/${T}_trace_last_call.txt 2>&1
+rm -rf $O/trace
+grep -A8 mt_jump $O/${T}_trace_last_call.txt
