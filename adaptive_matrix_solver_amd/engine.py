@@ -28,6 +28,7 @@ import weakref
 import numpy as np
 
 from . import _cabi
+from .candstore import C_NP, C_PY, EXACT, F_NP, F_PY, MISSING, CandidateStore, HistoryRecord
 from ._cabi import KIND_EIG, KIND_LINEAR, KIND_SVD, PERT_MT19937, PERT_NONE, PERT_UNIFORM, POP_U, POP_W, POP_X
 
 # reference constants (AMS:16-26) used by the step
@@ -38,6 +39,10 @@ SIGMA_SIMILARITY_TOL_ABS = 1e-6
 CONVERGENCE_RESIDUAL_TOL = 1e-8
 
 DIRECT, GMRES = "direct_solve", "iterative_gmres"
+
+
+import operator as _operator
+_SLOT_OF = _operator.attrgetter("_slot")
 
 
 class _SolveFailed(RuntimeError):
@@ -261,6 +266,7 @@ class DeviceEngine:
         self._typ_entry = None                  # (matrix obj, rms entry) for pert_matters
         self._free = []
         self._next_slot = 0
+        self.store = CandidateStore()           # per-candidate bookkeeping, indexed by slot (candstore.py)
         self.steps_executed = 0
 
     # ---- shared default engine (for stand-alone SolutionCandidate use) ----------------
@@ -294,6 +300,7 @@ class DeviceEngine:
             self._free = []
             self._next_slot = 0
             self._bound_b = None
+            self.store = CandidateStore()       # the slots start again at 0: candidates of the old shape keep the old store
 
     def pert_matters(self, psi) -> np.ndarray:
         """AMS:49-52 adds 0.15*psi*((U1-.5)+i(U2-.5)) to H for GMRES as for the direct solve.  The device GMRES shares one
@@ -328,9 +335,24 @@ class DeviceEngine:
         """Give a candidate a device slot (and free it when the object dies)."""
         self.bind_matrix(cand.problem_matrix)
         cand._engine = self
-        cand.param_history.ctx = self.ctx
+        cand._ph.ctx = self.ctx
         cand._slot = self.alloc_slot()
+        cand._st = self.store
+        self.store.init_slot(cand._slot)
+        self.store.records[cand._slot] = cand.__dict__.pop("_record_init", True)
+        self.store.mat_tag[cand._slot] = self._mat_tag(cand.problem_matrix)
+        cand._hist_seen = len(self.store.hist_log)
         weakref.finalize(cand, DeviceEngine._release, weakref.ref(self), cand._slot, id(self._bound))
+
+    def _mat_tag(self, M) -> int:
+        """Small integer per matrix OBJECT candidates were constructed on (the residual of AMS:295-301 is taken against that
+        object)."""
+        tags = self.__dict__.setdefault("_mat_tags", {})
+        t = tags.get(id(M))
+        if t is None or t[1]() is not M:                  # (an id can come back after its object has died)
+            self._mat_tag_next = getattr(self, "_mat_tag_next", 0) + 1
+            t = tags[id(M)] = (self._mat_tag_next, weakref.ref(M))
+        return t[0]
 
     @staticmethod
     def _release(eng_ref, slot, mat_id):
@@ -338,48 +360,70 @@ class DeviceEngine:
         if eng is not None and eng._bound is not None and id(eng._bound) == mat_id:
             eng.free_slot(slot)
 
-    def _bulk_pull(self, cands) -> None:
+    @staticmethod
+    def _slots(cands) -> np.ndarray:
+        return np.fromiter(map(_SLOT_OF, cands), dtype=np.int64, count=len(cands))
+
+    def _bulk_pull(self, cands, slots=None) -> None:
         """Refresh stale host mirrors of many candidates with one transfer per array."""
         from .solver import ProblemType
-        stale = [c for c in cands if not c._host_valid]
-        if not stale:
+        if not cands:
             return
-        slots = [c._slot for c in stale]
-        X = self.ctx.pop_get(POP_X, slots, stale[0]._len_v())
+        st = self.store
+        if slots is None:
+            slots = self._slots(cands)
+        ix = np.nonzero(~st.host_valid[slots])[0]
+        if not ix.size:
+            return
+        stale = [cands[k] for k in ix.tolist()]
+        sl = slots[ix]
+        X = self.ctx.pop_get(POP_X, sl, stale[0]._len_v())
         U = None
         if stale[0].problem_type == ProblemType.SVD:
-            U = self.ctx.pop_get(POP_U, slots, stale[0].M_rows)
+            U = self.ctx.pop_get(POP_U, sl, stale[0].M_rows)
         for k, c in enumerate(stale):
             c._hv = X[k]
             if U is not None:
                 c._hu = U[k]
-            c._host_valid = True
+        st.host_valid[sl] = True
 
-    def _stage_history(self, cands) -> None:
-        """Before SolutionCandidate._record_history (AMS:303-304): small problems get their host mirrors refreshed with
-        one transfer; above n = 512 the vectors are appended device-to-device to the history store and the candidates
-        keep a reference (SURVEY f-4: device-backed param_history, pulled on access)."""
+    def _log_history(self, cands, slots) -> None:
+        """AMS:303-304 for every stepped candidate: param_history.append(get_current_solution_params()),
+        residual_history.append(residual_k).  Small problems (n <= 512): the host mirrors are refreshed with one transfer and
+        every candidate appends its tuple.  Above that the vectors are appended device-to-device to the history store (SURVEY
+        f-4: device-backed param_history, pulled on access) and the step leaves ONE record in the store's log -- the
+        candidates' lists catch up when somebody reads them (SolutionCandidate._replay_history), so a loop body does not
+        touch 6 144 Python objects to remember what it did."""
         from .solver import ProblemType
-        rec = [c for c in cands if c._record]
-        eager = [c for c in rec if not c._lazy_hist]
-        if eager:
-            self._bulk_pull(eager)
-        lazy = [c for c in rec if c._lazy_hist]
-        if lazy:
-            slots = [c._slot for c in lazy]
-            svd = lazy[0].problem_type == ProblemType.SVD
-            lv = lazy[0]._len_v()
-            iv = self.ctx.hist_append(POP_X, slots, lv)
-            iu = self.ctx.hist_append(POP_U, slots, lazy[0].M_rows) if svd else None
+        c0 = cands[0]
+        st = self.store
+        if not c0._lazy_hist:
+            ix = np.nonzero(st.records[slots])[0]
+            if ix.size:
+                self._bulk_pull(cands if ix.size == len(cands) else [cands[k] for k in ix.tolist()], slots[ix])
+            for c in cands:
+                c._record_history()
+            return
+        recording = st.records[slots]
+        href = None
+        hidx = None
+        if recording.any():
+            rs = slots if recording.all() else slots[recording]
+            svd = c0.problem_type == ProblemType.SVD
+            lv = c0._len_v()
+            iv = self.ctx.hist_append(POP_X, rs, lv)
+            iu = self.ctx.hist_append(POP_U, rs, c0.M_rows) if svd else None
             gen = self.ctx.hist_generation() if hasattr(self.ctx, "hist_generation") else 0      # once per step, not per candidate
-            # flat tuples of ints: the compact history reference without its tag and scalar (SolutionCandidate._record_history adds them)
-            if svd:
-                lu = lazy[0].M_rows
-                for k, c in enumerate(lazy):
-                    c._hist_ref = (gen, iu + k, lu, iv + k, lv)
-            else:
-                for k, c in enumerate(lazy):
-                    c._hist_ref = (gen, iv + k, lv)
+            href = (gen, iu, c0.M_rows, iv, lv) if svd else (gen, iv, lv)
+            hidx = np.where(recording, np.cumsum(recording) - 1, -1)
+        kind = c0.problem_type
+        if kind == ProblemType.EIGENVALUE:
+            scal, cplx = (st.lam[slots], st.lam_kind[slots], st.lam_obj[slots]), True
+        elif kind == ProblemType.SVD:
+            scal, cplx = (st.sig[slots], st.sig_kind[slots], st.sig_obj[slots]), False
+        else:
+            scal, cplx = None, False
+        st.hist_log.append(HistoryRecord(slots.copy(), (st.res[slots], st.res_kind[slots], st.res_obj[slots]), scal, cplx, hidx, href))
 
     # ---- perturbation mode ---------------------------------------------------------------
     def _pert(self, n: int) -> int:
@@ -477,10 +521,10 @@ class DeviceEngine:
             loc = self.ctx.relax_normalise([cands[k]._slot for k in mine], alpha[mine], normalise=normalise)[:, None]
         return self._exchange(cands, loc)[:, 0]
 
-    def d_residual(self, kind, cands, lam):
+    def d_residual(self, kind, cands, lam, slots=None):
         mine = self._mine(cands)
         if mine is None:
-            return self.ctx.residual(kind, [c._slot for c in cands], lam)
+            return self.ctx.residual(kind, self._slots(cands) if slots is None else slots, lam)
         loc = np.zeros((len(mine), 2))
         if mine:
             res, fin = self.ctx.residual(kind, [cands[k]._slot for k in mine], None if lam is None else lam[mine])
@@ -488,19 +532,23 @@ class DeviceEngine:
         f = self._exchange(cands, loc)
         return f[:, 0], f[:, 1] != 0
 
-    def d_svd_power(self, cands):
+    def d_svd_power(self, cands, slots=None):
         """Speculative power step: norms only, the candidates' vectors stay as they are (d_svd_commit applies it)."""
         mine = self._mine(cands)
         if mine is None:
-            return self.ctx.svd_power_propose([c._slot for c in cands])
+            return self.ctx.svd_power_propose(self._slots(cands) if slots is None else slots)
         loc = np.zeros((len(mine), 4))
         if mine:
             loc = self.ctx.svd_power_propose([cands[k]._slot for k in mine])
         return self._exchange(cands, loc)
 
-    def d_svd_commit(self, cands):
+    def d_svd_commit(self, cands, slots=None):
         mine = self._mine(cands)
-        own = cands if mine is None else [cands[k] for k in mine]
+        if mine is None:
+            if cands:
+                self.ctx.svd_commit(self._slots(cands) if slots is None else slots)
+            return
+        own = [cands[k] for k in mine]
         if own:
             self.ctx.svd_commit([c._slot for c in own])
 
@@ -549,7 +597,7 @@ class DeviceEngine:
     # ======================================================================================
     # the step
     # ======================================================================================
-    def step(self, cands, A, b, strat, know) -> None:
+    def step(self, cands, A, b, strat, know, slots=None) -> None:
         """update_solution_step for every candidate of `cands` (list order = RNG order)."""
         if not cands:
             return
@@ -565,25 +613,29 @@ class DeviceEngine:
         if self.comm is not None:
             own = self.comm.owners(len(cands))
             self._owner = {id(c): int(own[k]) for k, c in enumerate(cands)}
+        st = self.store
+        if slots is None or len(slots) != len(cands):
+            slots = self._slots(cands)
         if need_backup:
-            self._bulk_pull(cands)
-        for c in cands:
-            c.b_vector = b                                  # AMS:146
-            c.prev_residual = c.residual_k                  # AMS:147
-            if not c._dev_valid:
-                c._push()                                   # make sure device rows are current
+            self._bulk_pull(cands, slots)
+        st.set_all("b_obj", slots, b)                       # AMS:146
+        st.copy_real("prev", "res", slots)                  # AMS:147
+        for k in np.nonzero(~st.dev_valid[slots])[0].tolist():
+            cands[k]._push()                                # make sure device rows are current
         self.steps_executed += len(cands)
 
         todo = list(cands)
         if kind == ProblemType.EIGENVALUE and know.get("is_hermitian", False):   # AMS:155
-            todo = self._hermitian(todo, A)
+            todo = self._hermitian(todo, A, slots)
+            if todo:
+                slots = self._slots(todo)
         if todo:
             if kind == ProblemType.SVD:
-                self._svd(todo, A, strat)
+                self._svd(todo, A, strat, slots)
             else:
                 self._solve(todo, A, b, strat, know)
             self._sync_rows(todo)                       # peers' updated rows, before anything reads them back
-            self._finish(todo, A, b, strat)
+            self._finish(todo, A, b, strat, slots)
 
     # ---- Hermitian shortcut (AMS:155-221) ----------------------------------------------
     def seed_eigh(self, A, evals, evecs):
@@ -677,7 +729,7 @@ class DeviceEngine:
         comm.bcast_eigvecs(self.ctx, evecs, n)
         self._eig_cache = (A, ev)
 
-    def _hermitian(self, cands, A):
+    def _hermitian(self, cands, A, slots):
         from .solver import SolutionCandidate
         S = SolutionCandidate.State
         if self._eig_cache is not None and self._eig_cache[0] is not A and self._eig_cache[0].shape == A.shape \
@@ -694,61 +746,63 @@ class DeviceEngine:
         idx, _ = self.d_herm_match(cands)
         lam = evals[idx]
         res, _fin = self.d_residual(KIND_EIG, cands, lam.astype(np.complex128))
-        for c in cands:
-            c._invalidate()
+        st = self.store
+        st.host_valid[slots] = False                       # _invalidate(): the device rows are the new state
+        st.dev_valid[slots] = True
         self._sync_rows(cands)
+        # lambda_k = evals[idx] keeps the dtype of the eigenvalue array (np.float64 from eigh): assigned as objects
         for k, c in enumerate(cands):
             c.lambda_k = lam[k]
-            c._invalidate()
-        self._stage_history(cands)
-        for k, c in enumerate(cands):
-            c.residual_k = res[k]
-            c.state = S.CONVERGED
-            c.stuck_counter = 0
-            c.local_psi_retries_needed = 0
-            c.w_k = 1.0
-            c._record_history()
+        st.set_real("res", slots, res, F_NP)
+        st.state[slots] = S.CONVERGED.value
+        st.stuck[slots] = 0
+        st.retries[slots] = 0
+        st.set_real("w", slots, 1.0, F_PY)
+        self._log_history(cands, slots)
         return []
 
     # ---- SVD alternating power step (AMS:227-255) -----------------------------------------
-    def _svd(self, cands, A, strat):
+    def _svd(self, cands, A, strat, slots):
         from .solver import SolutionCandidate
         S = SolutionCandidate.State
+        st = self.store
         tiny = SIGMA_SIMILARITY_TOL_ABS / 100
         i = 0
         while i < len(cands):
             run = cands[i:]
+            rslots = slots[i:]
             # speculative: the whole run; norms = (||v_in||, sigma1, ||u||, sigma2).  Nothing is written to the candidates'
             # vectors until the commit below, so the candidates behind an event need no restoring
-            norms = self.d_svd_power(run)
+            norms = self.d_svd_power(run, rslots)
             # first candidate that takes an exceptional branch
             bad = (norms[:, 0] < 1e-10) | (norms[:, 2] < 1e-10) | ~np.isfinite(norms).all(axis=1)
             ev = int(np.argmax(bad)) if bad.any() else None
             good = run if ev is None else run[:ev]
-            self.d_svd_commit(good)
             ng = len(good)
+            gs = rslots[:ng]
+            self.d_svd_commit(good, gs)
             sig = np.where(norms[:ng, 3] > norms[:ng, 1], norms[:ng, 3], norms[:ng, 1])   # max(s1, s2), AMS:234, 241 (finite here)
-            conv = (sig < tiny).tolist()
-            for k, c in enumerate(good):
-                c.sigma_k = sig[k]
-                c._host_valid = False                                     # _invalidate(): the device rows are the new state
-                c._dev_valid = True
-                if conv[k]:                                               # AMS:243-247
-                    c.residual_k = strat.get("current_convergence_threshold", 1e-6) * 0.1
-                    c.state = S.CONVERGED
-                    c.stuck_counter = 0
-                    # AMS:246-247: a collapsed u_k / right_v_k is replaced by ones/sqrt(dim).  ||u_k|| is norms[k, 2]
-                    # (a collapse there has already left through the exception path, like AMS:236-239 raises before
-                    # these lines); right_v_k = s / (sigma2 if sigma2 > 1e-10 else 1), so its norm is below 1e-10
-                    # exactly when sigma2 is.  Reachable only at a rounding knife edge.
-                    if norms[k, 2] < 1e-10:
-                        c.u_k = np.ones(c.M_rows, dtype=np.complex128) / np.sqrt(c.M_rows)
-                        c._push(force=True)
-                    if norms[k, 3] < 1e-10:
-                        c.right_v_k = np.ones(c.M_cols, dtype=np.complex128) / np.sqrt(c.M_cols)
-                        c._push(force=True)
-                elif c.stuck_counter:
-                    c.stuck_counter -= 1                                  # max(0, stuck - 1)
+            st.set_real("sig", gs, sig, F_NP)
+            st.host_valid[gs] = False                                     # _invalidate(): the device rows are the new state
+            st.dev_valid[gs] = True
+            conv = sig < tiny
+            for k in np.nonzero(conv)[0].tolist():                        # AMS:243-247
+                c = good[k]
+                c.residual_k = strat.get("current_convergence_threshold", 1e-6) * 0.1
+                c.state = S.CONVERGED
+                c.stuck_counter = 0
+                # AMS:246-247: a collapsed u_k / right_v_k is replaced by ones/sqrt(dim).  ||u_k|| is norms[k, 2]
+                # (a collapse there has already left through the exception path, like AMS:236-239 raises before
+                # these lines); right_v_k = s / (sigma2 if sigma2 > 1e-10 else 1), so its norm is below 1e-10
+                # exactly when sigma2 is.  Reachable only at a rounding knife edge.
+                if norms[k, 2] < 1e-10:
+                    c.u_k = np.ones(c.M_rows, dtype=np.complex128) / np.sqrt(c.M_rows)
+                    c._push(force=True)
+                if norms[k, 3] < 1e-10:
+                    c.right_v_k = np.ones(c.M_cols, dtype=np.complex128) / np.sqrt(c.M_cols)
+                    c._push(force=True)
+            dec = gs[~conv] if conv.any() else gs
+            st.stuck[dec] = np.maximum(st.stuck[dec] - 1, 0)              # max(0, stuck - 1), AMS:248
             if ev is None:
                 break
             self._svd_exception(run[ev], norms[ev])
@@ -1136,66 +1190,67 @@ class DeviceEngine:
                 c.initialize_random_solution()                           # E5
 
     # ---- residual, histories, alpha/state adaptation, convergence (AMS:295-331) -------------
-    def _finish(self, cands, A, b, strat):
+    def _finish(self, cands, A, b, strat, slots=None):
         """Residuals (AMS:295-301), histories (AMS:303-304), alpha / state adaptation (AMS:306-316) and the convergence test
-        (AMS:318-331) of every stepped candidate.  The decisions are taken on arrays over the whole list and applied in one
-        pass (at 6144 candidates -- BASELINE configs[4] -- per-candidate NumPy scalar arithmetic was 40 ms per loop body,
-        more than the body's kernels)."""
+        (AMS:318-331) of every stepped candidate, on the arrays of the candidate store: no Python object is touched per
+        candidate (at 6144 candidates -- BASELINE configs[4] -- per-candidate NumPy scalar arithmetic was 40 ms per loop body
+        in round 2, the per-candidate application of array decisions 8 ms in round 3)."""
         from .solver import ProblemType, SolutionCandidate
         S = SolutionCandidate.State
+        st = self.store
         kind = cands[0].problem_type
         n = len(cands)
+        if slots is None or len(slots) != n:
+            slots = self._slots(cands)
         resv = np.empty(n, dtype=np.float64)
         okv = np.empty(n, dtype=bool)
         # residual against the construction-time matrix of each candidate (SURVEY F9): one group -- the whole list, no index
         # bookkeeping -- unless somebody mixed candidates of different matrix objects
-        mats = {id(c.problem_matrix) for c in cands}
-        if len(mats) == 1:
-            pos = None
-            groups = {0: cands}
+        tags = st.mat_tag[slots]
+        if (tags == tags[0]).all():
+            groups = {0: (cands, slice(None))}
         else:
-            pos = {id(c): k for k, c in enumerate(cands)}
             groups = {}
-            for c in cands:
-                groups.setdefault(id(c.problem_matrix), []).append(c)
+            for t in np.unique(tags).tolist():
+                ks = np.nonzero(tags == t)[0]
+                groups[t] = ([cands[k] for k in ks.tolist()], ks)
         pre = getattr(self, "_pre_resid", None) or {}
         if pre and all(id(c) in pre for c in cands):
             # the owners' residuals came with the step's record (_share_step): no second exchange
+            lamfin = np.isfinite(st.lam[slots]) if kind == ProblemType.EIGENVALUE else np.ones(n, dtype=bool)
             for k, c in enumerate(cands):
                 r, fin = pre[id(c)]
                 resv[k] = r
-                okv[k] = bool(fin) and (kind != ProblemType.EIGENVALUE or bool(np.isfinite(complex(c.lambda_k))))
-                c.residual_k = resv[k]
+                okv[k] = bool(fin) and bool(lamfin[k])
             groups = {}
         self._pre_resid = {}
-        for _, grp in groups.items():
+        for _, (grp, ix) in groups.items():
             self.bind_matrix(grp[0].problem_matrix)
-            ix = slice(None) if pos is None else np.fromiter((pos[id(c)] for c in grp), dtype=np.int64, count=len(grp))
+            gsl = slots[ix]
             if kind == ProblemType.EIGENVALUE:
-                lam = np.array([complex(c.lambda_k) for c in grp], dtype=np.complex128)
-                res, fin = self.d_residual(KIND_EIG, grp, lam)
+                lam = st.lam[gsl]                                          # complex(c.lambda_k) of every candidate
+                res, fin = self.d_residual(KIND_EIG, grp, lam, gsl)
                 fin = np.asarray(fin, dtype=bool) & np.isfinite(lam)
             elif kind == ProblemType.SOLVE_LINEAR_SYSTEM:
-                res, fin = self.d_residual(KIND_LINEAR, grp, None)
+                res, fin = self.d_residual(KIND_LINEAR, grp, None, gsl)
                 fin = np.asarray(fin, dtype=bool)
             else:
-                sig = np.array([complex(c.sigma_k) for c in grp], dtype=np.complex128)
-                res, fin = self.d_residual(KIND_SVD, grp, sig)
+                sig = st.sig[gsl].astype(np.complex128)                    # complex(c.sigma_k)
+                res, fin = self.d_residual(KIND_SVD, grp, sig, gsl)
                 fin = np.asarray(fin, dtype=bool) & np.isfinite(sig)
             resv[ix] = res
             okv[ix] = fin
-            for c, r in zip(grp, res):                   # (iterating the array yields the np.float64 scalars res[k] would)
-                c.residual_k = r
+        st.set_real("res", slots, resv, F_NP)                              # residual_k = the np.float64 norm (AMS:295-301)
         self.bind_matrix(A)
         thr = strat.get("current_convergence_threshold", CONVERGENCE_RESIDUAL_TOL)
-        self._stage_history(cands)
-        prev = np.array([c.prev_residual for c in cands], dtype=np.float64)
+        self._log_history(cands, slots)                                    # AMS:303-304
+        prev = st.prev[slots]
         # alpha is np.complex128(0.01) in the reference (AMS:17, imaginary part always 0) and keeps that type through
         # `alpha * 1.1` etc. until a clamp hands back the Python-float bound (AMS:308, 311, 314: min / max return one of their
         # arguments; NumPy orders complex scalars lexicographically) or convergence sets 0.0 (AMS:331); from then on it is a
-        # Python float.  The arithmetic is done on arrays, the types are restored per candidate below.
-        alpha_old = [c.alpha_local_step for c in cands]
-        alpha = np.array([a.real for a in alpha_old], dtype=np.float64)
+        # Python float.  The store keeps the value and which of the two types it has.
+        alpha = st.alpha[slots]
+        akind = st.alpha_kind[slots]
         with np.errstate(invalid="ignore", over="ignore"):
             live = prev > 1e-10                                                  # AMS:306
             m1 = live & (resv < prev * 0.9)                                      # AMS:307 -> REFINING
@@ -1205,29 +1260,29 @@ class DeviceEngine:
             clamped = np.where(m1, raw > 1.0, raw < 1e-6)                        # min(x, 1.0) is 1.0 iff 1.0 < x; max(x, 1e-6) is 1e-6 iff x < 1e-6
             new_alpha = np.where(clamped, np.where(m1, 1.0, 1e-6), raw)
             conv = (resv < thr) & okv                                            # AMS:318-331
-        code = (m1 * 1 + m2 * 2 + m3 * 3).tolist()
-        c128 = np.complex128
-        alpha_c = list(new_alpha.astype(c128))          # the same values as np.complex128 scalars (the type an unclamped alpha keeps)
-        new_alpha = new_alpha.tolist()
-        clamped = clamped.tolist()
-        conv = conv.tolist()
-        CONV, STUCK, RETIRED = S.CONVERGED, S.STUCK, S.RETIRED
-        for k, c in enumerate(cands):
-            c._record_history()                                          # AMS:303-304
-            cd = code[k]
-            if cd:
-                c.alpha_local_step = new_alpha[k] if (clamped[k] or type(alpha_old[k]) is not c128) else alpha_c[k]
-                st = c.state
-                if cd == 1:
-                    if st is not CONV:
-                        c.state = S.REFINING
-                elif cd == 2:
-                    if st is not CONV:
-                        c.state = STUCK
-                elif st is not CONV and st is not STUCK and st is not RETIRED:
-                    c.state = S.EXPLORING
-            if conv[k]:
-                c.state = CONV
-                c.w_k = 1.0
-                c.stuck_counter = 0
-                c.alpha_local_step = 0.0
+        odd = akind == EXACT                       # an alpha of some other type that a caller assigned: that candidate alone, as objects
+        stc = st.state[slots]
+        CONV, STUCK, RETIRED = S.CONVERGED.value, S.STUCK.value, S.RETIRED.value
+        open_ = stc != CONV
+        new_state = stc.copy()
+        new_state[m1 & open_] = S.REFINING.value
+        new_state[m2 & open_] = STUCK
+        new_state[m3 & open_ & (stc != STUCK) & (stc != RETIRED)] = S.EXPLORING.value
+        new_state[conv] = CONV
+        st.state[slots] = new_state
+        upd = live & ~odd
+        if upd.any():
+            us = slots[upd]
+            st.alpha[us] = new_alpha[upd]
+            st.alpha_kind[us] = np.where(clamped[upd] | (akind[upd] == C_PY), C_PY, C_NP)
+            st.alpha_obj[us] = MISSING
+        for k in np.nonzero(odd & live)[0].tolist():
+            c, a = cands[k], cands[k].alpha_local_step
+            c.alpha_local_step = min(a * 1.1, 1.0) if m1[k] else (max(a * 0.5, 1e-6) if m2[k] else max(a * 0.95, 1e-6))
+        if conv.any():
+            cs = slots[conv]
+            st.set_real("w", cs, 1.0, F_PY)
+            st.stuck[cs] = 0
+            st.alpha[cs] = 0.0
+            st.alpha_kind[cs] = C_PY
+            st.alpha_obj[cs] = MISSING

@@ -26,6 +26,7 @@ import numpy as np
 
 from . import _cabi
 from ._cabi import POP_U, POP_X
+from .candstore import C_NP as _C_NP, C_PY as _C_PY, EXACT as _EXACT, F_NP as _F_NP, F_PY as _F_PY, HREF as _HREF, MISSING as _MISSING
 from .engine import DIRECT, GMRES, DeviceEngine, _advance_numpy_stream
 
 
@@ -40,6 +41,19 @@ GLOBAL_DEFAULT_PSI_EPSILON_BASE = np.complex128(1e-20)
 GLOBAL_DEFAULT_ALPHA_V_INITIAL = np.complex128(0.01)
 REFERENCE_LAZY_MIN = 512          # evolve(): general eigenvalues of larger matrices are computed when true_solution is first read
 _DEFERRED = object()
+
+
+def _classify_real(v):
+    """(numeric mirror, kind) of a value assigned to a real-valued candidate attribute (candstore.py)."""
+    t = type(v)
+    if t is np.float64:
+        return v, _F_NP
+    if t is float:
+        return v, _F_PY
+    try:
+        return float(v), _EXACT
+    except (TypeError, ValueError):
+        return np.nan, _EXACT
 GLOBAL_MAX_PSI_ATTEMPTS = 25
 GLOBAL_MAX_STUCK_FOR_RETIREMENT = 8
 GLOBAL_MIN_WEIGHT_TO_SURVIVE_PRUNE = 1e-10
@@ -203,7 +217,7 @@ class _HistRef:
         return vecs if self.scalar is None else (self.scalar,) + vecs
 
 
-_HREF = "\x00maus-history-row"        # first item of a compact history reference (see _LazyHistory)
+# _HREF (candstore.HREF): first item of a compact history reference (see _LazyHistory)
 
 
 # A recorded iterate whose vectors live in the device history store is kept in param_history as an exact tuple of atoms
@@ -263,21 +277,23 @@ class SolutionCandidate:
         self.M_rows, self.M_cols = problem_matrix.shape
         self.problem_type = problem_type
         self.problem_matrix = problem_matrix
-        self.b_vector = None
-        self.lambda_k = initial_lambda
-        self.sigma_k = initial_sigma
         # host mirrors of the device rows; _hv = POP_X row (v_k | x_k | right_v_k), _hu = POP_U row (u_k)
         self._hv = None
         self._hu = None
-        self._host_valid = True        # host mirrors are current
-        self._dev_valid = False        # device rows are current
         self._slot = None
         self._engine = None
         # param_history records every iterate like the reference (record_history=False: residual_history only); above
         # n = 512 the vectors stay on the device (history store) until somebody reads them
-        self._record = True if record_history is None else bool(record_history)
+        self._record_init = True if record_history is None else bool(record_history)      # moves into the store at attach
         self._lazy_hist = max(self.M_rows, self.M_cols) > 512
-        self._hist_ref = None
+        self._ph = _LazyHistory()
+        self._rh = []
+        # the bookkeeping of AMS:113-126 lives in the engine's structure-of-arrays store under this candidate's slot
+        # (candstore.py); the attributes below are views of it
+        (engine or DeviceEngine.default()).attach(self)
+        self.b_vector = None
+        self.lambda_k = initial_lambda
+        self.sigma_k = initial_sigma
         self.state = SolutionCandidate.State.EXPLORING
         self.w_k = initial_weight
         self.residual_k = float("inf")
@@ -286,10 +302,218 @@ class SolutionCandidate:
         self.stuck_counter = 0
         self.local_psi_retries_needed = 0
         self.num_resets = 0
-        self.param_history = _LazyHistory()
-        self.residual_history = []
-        (engine or DeviceEngine.default()).attach(self)
         self.initialize_random_solution()                     # overwrites any seeds (AMS:127)
+
+    # ---- views of the structure-of-arrays store (candstore.py) -----------------------------------
+    # Each getter hands out the object the reference's attribute would hold (same value, same scalar type) and caches it;
+    # each setter keeps the assigned object and mirrors its numeric value for the array code of the engine.
+    @property
+    def residual_k(self):
+        st, s = self._st, self._slot
+        o = st.res_obj[s]
+        if o is _MISSING:
+            x = st.res[s]
+            o = st.res_obj[s] = x if st.res_kind[s] == _F_NP else float(x)
+        return o
+
+    @residual_k.setter
+    def residual_k(self, v):
+        st, s = self._st, self._slot
+        st.res[s], st.res_kind[s] = _classify_real(v)
+        st.res_obj[s] = v
+
+    @property
+    def prev_residual(self):
+        st, s = self._st, self._slot
+        o = st.prev_obj[s]
+        if o is _MISSING:
+            x = st.prev[s]
+            o = st.prev_obj[s] = x if st.prev_kind[s] == _F_NP else float(x)
+        return o
+
+    @prev_residual.setter
+    def prev_residual(self, v):
+        st, s = self._st, self._slot
+        st.prev[s], st.prev_kind[s] = _classify_real(v)
+        st.prev_obj[s] = v
+
+    @property
+    def w_k(self):
+        st, s = self._st, self._slot
+        o = st.w_obj[s]
+        if o is _MISSING:
+            x = st.w[s]
+            o = st.w_obj[s] = x if st.w_kind[s] == _F_NP else float(x)
+        return o
+
+    @w_k.setter
+    def w_k(self, v):
+        st, s = self._st, self._slot
+        st.w[s], st.w_kind[s] = _classify_real(v)
+        st.w_obj[s] = v
+
+    @property
+    def sigma_k(self):
+        st, s = self._st, self._slot
+        o = st.sig_obj[s]
+        if o is _MISSING:
+            x = st.sig[s]
+            o = st.sig_obj[s] = x if st.sig_kind[s] == _F_NP else float(x)
+        return o
+
+    @sigma_k.setter
+    def sigma_k(self, v):
+        st, s = self._st, self._slot
+        st.sig[s], st.sig_kind[s] = _classify_real(v)
+        st.sig_obj[s] = v
+
+    @property
+    def alpha_local_step(self):
+        st, s = self._st, self._slot
+        o = st.alpha_obj[s]
+        if o is _MISSING:
+            x = st.alpha[s]
+            o = st.alpha_obj[s] = np.complex128(x) if st.alpha_kind[s] == _C_NP else float(x)
+        return o
+
+    @alpha_local_step.setter
+    def alpha_local_step(self, v):
+        st, s = self._st, self._slot
+        t = type(v)
+        if t is np.complex128 and v.imag == 0.0:
+            st.alpha[s], st.alpha_kind[s] = v.real, _C_NP
+        elif t is float:
+            st.alpha[s], st.alpha_kind[s] = v, _C_PY
+        else:
+            st.alpha_kind[s] = _EXACT
+            try:
+                st.alpha[s] = complex(v).real
+            except (TypeError, ValueError):
+                st.alpha[s] = np.nan
+        st.alpha_obj[s] = v
+
+    @property
+    def lambda_k(self):
+        st, s = self._st, self._slot
+        o = st.lam_obj[s]
+        if o is _MISSING:
+            z = st.lam[s]
+            o = st.lam_obj[s] = z if st.lam_kind[s] == _C_NP else complex(z)
+        return o
+
+    @lambda_k.setter
+    def lambda_k(self, v):
+        st, s = self._st, self._slot
+        t = type(v)
+        if t is np.complex128:
+            st.lam[s], st.lam_kind[s] = v, _C_NP
+        elif t is complex:
+            st.lam[s], st.lam_kind[s] = v, _C_PY
+        else:
+            st.lam_kind[s] = _EXACT
+            try:
+                st.lam[s] = complex(v)
+            except (TypeError, ValueError):
+                st.lam[s] = np.nan
+        st.lam_obj[s] = v
+
+    @property
+    def state(self):
+        return _STATE_BY_CODE[self._st.state[self._slot]]
+
+    @state.setter
+    def state(self, v):
+        self._st.state[self._slot] = v.value
+
+    @property
+    def stuck_counter(self):
+        return int(self._st.stuck[self._slot])
+
+    @stuck_counter.setter
+    def stuck_counter(self, v):
+        self._st.stuck[self._slot] = v
+
+    @property
+    def local_psi_retries_needed(self):
+        return int(self._st.retries[self._slot])
+
+    @local_psi_retries_needed.setter
+    def local_psi_retries_needed(self, v):
+        self._st.retries[self._slot] = v
+
+    @property
+    def num_resets(self):
+        return int(self._st.resets[self._slot])
+
+    @num_resets.setter
+    def num_resets(self, v):
+        self._st.resets[self._slot] = v
+
+    @property
+    def b_vector(self):
+        return self._st.b_obj[self._slot]
+
+    @b_vector.setter
+    def b_vector(self, v):
+        self._st.b_obj[self._slot] = v
+
+    @property
+    def _record(self):
+        return bool(self._st.records[self._slot])
+
+    @_record.setter
+    def _record(self, v):
+        self._st.records[self._slot] = bool(v)
+
+    @property
+    def _host_valid(self):                 # host mirrors are current
+        return bool(self._st.host_valid[self._slot])
+
+    @_host_valid.setter
+    def _host_valid(self, v):
+        self._st.host_valid[self._slot] = v
+
+    @property
+    def _dev_valid(self):                  # device rows are current
+        return bool(self._st.dev_valid[self._slot])
+
+    @_dev_valid.setter
+    def _dev_valid(self, v):
+        self._st.dev_valid[self._slot] = v
+
+    # ---- histories (AMS:126, 303-304) ---------------------------------------------------------------
+    # Above n = 512 the batched step does not touch the candidate objects: the engine logs one record per step
+    # (DeviceEngine._log_history) and the lists are brought up to date when somebody reads them.
+    def _replay_history(self):
+        log = self._st.hist_log
+        n = len(log)
+        k = self._hist_seen
+        if k < n:
+            slot = self._slot
+            while k < n:
+                log[k].replay(slot, self._rh, self._ph if self._record else None)
+                k += 1
+            self._hist_seen = n
+
+    @property
+    def param_history(self):
+        self._replay_history()
+        return self._ph
+
+    @param_history.setter
+    def param_history(self, v):
+        self._replay_history()
+        self._ph = v
+
+    @property
+    def residual_history(self):
+        self._replay_history()
+        return self._rh
+
+    @residual_history.setter
+    def residual_history(self, v):
+        self._replay_history()
+        self._rh = v
 
     # ---- host <-> device mirrors --------------------------------------------------------------
     def _len_v(self):
@@ -401,17 +625,11 @@ class SolutionCandidate:
         self.residual_history.append(self.residual_k)
 
     def _record_history(self):
-        """AMS:303-304.  The engine stages the vectors first (DeviceEngine._stage_history): a host pull for small
-        problems, a device-to-device append to the history store (self._hist_ref) above n = 512."""
+        """AMS:303-304 for a candidate whose vectors are recorded from the host mirrors (n <= 512; the engine refreshed them
+        with one transfer, DeviceEngine._log_history).  Larger problems never get here: their steps are logged by the engine."""
         if self._record:
-            if self._hist_ref is not None:
-                pt = self.problem_type
-                scalar = self.lambda_k if pt == ProblemType.EIGENVALUE else (self.sigma_k if pt == ProblemType.SVD else None)
-                self.param_history.append((_HREF, scalar) + self._hist_ref)   # staged by the engine: (generation, index, length, ...)
-                self._hist_ref = None
-            else:
-                self.param_history.append(self.get_current_solution_params())
-        self.residual_history.append(self.residual_k)
+            self._ph.append(self.get_current_solution_params())
+        self._rh.append(self.residual_k)
 
     # ---- AMS:145-331 -----------------------------------------------------------------------------
     def update_solution_step(self, current_matrix_A, b_vector=None, strat_params=None, global_knowledge=None):
@@ -427,6 +645,10 @@ class SolutionCandidate:
         elif self.problem_type == ProblemType.SVD:
             return (self.sigma_k, self.u_k, self.right_v_k)
         return None
+
+
+_STATE_BY_CODE = (None,) + tuple(SolutionCandidate.State)          # State.value -> member (candstore.py keeps the value)
+_CONV, _RETIRED = SolutionCandidate.State.CONVERGED.value, SolutionCandidate.State.RETIRED.value
 
 
 # ==========================================================================================
@@ -632,28 +854,54 @@ class MAUS_Solver:
                 sp_["overall_psi_aggression_factor"] = max(sp_["overall_psi_aggression_factor"], 2.0)
             sp_["current_convergence_threshold"] = max(1e-5, sp_["convergence_tolerance"])
 
-    def _prefetch_converged(self):
+    def _pop_view(self):
+        """(store, slots, state codes) of self.candidates: the population as arrays (candstore.py).  The slot array is kept
+        between calls and rebuilt when the list is another object or another length than last time (spot-checked at three
+        positions: the solver itself only ever replaces the list or appends to it)."""
+        cl = self.candidates
+        n = len(cl)
+        if not n:
+            return None, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.uint8)
+        st = cl[0]._st
+        cache = self.__dict__.get("_view_cache")
+        if (cache is not None and cache[0] is cl and len(cache[1]) == n and cl[0]._slot == cache[1][0]
+                and cl[-1]._slot == cache[1][-1] and cl[n // 2]._slot == cache[1][n // 2]):
+            slots = cache[1]
+        else:
+            slots = DeviceEngine._slots(cl)
+            self._view_cache = (cl, slots)
+        return st, slots, st.state[slots]
+
+    def _prefetch_converged(self, view=None):
         """Host mirrors of the CONVERGED candidates' vectors with one transfer per array (AMS:432 / 510 read every one of them
         through get_current_solution_params; one device-to-host copy per candidate was 40 us each -- 8 ms in the loop body in
         which a few hundred candidates converge together)."""
-        C = SolutionCandidate.State
-        stale = [c for c in self.candidates if c.state == C.CONVERGED and not c._host_valid and c._engine is self.engine]
-        if len(stale) > 1:
-            self.engine._bulk_pull(stale)
+        st, slots, code = view if view is not None else self._pop_view()
+        if st is None:
+            return
+        ix = np.nonzero((code == _CONV) & ~st.host_valid[slots])[0]
+        if ix.size > 1:
+            stale = [self.candidates[k] for k in ix.tolist()]
+            if all(c._engine is self.engine for c in stale):
+                self.engine._bulk_pull(stale, slots[ix])
+            else:
+                self.engine._bulk_pull([c for c in stale if c._engine is self.engine])
 
     # ---- AMS:424-475 ------------------------------------------------------------------------------
-    def _converged_gram(self):
+    def _converged_gram(self, view=None):
         """(position map, |Gram| blocks) over the CONVERGED candidates in list order, or (None, None) when the set is
         small / the problem type has no vector test.  EIG: {'v'}; SVD: {'u', 'v'}."""
-        from ._cabi import POP_U, POP_X
-        C = SolutionCandidate.State
         if self.problem_type not in (ProblemType.EIGENVALUE, ProblemType.SVD):
             return None, None
-        conv = [c for c in self.candidates if c.state == C.CONVERGED]
-        if len(conv) < max(2, self.gram_min):
+        st, slots, code = view if view is not None else self._pop_view()
+        if st is None:
             return None, None
-        for c in conv:
-            c._push()                                    # host-side edits (if any) reach the device rows first
+        ix = np.nonzero(code == _CONV)[0]
+        if ix.size < max(2, self.gram_min):
+            return None, None
+        conv = [self.candidates[k] for k in ix.tolist()]
+        for k in np.nonzero(~st.dev_valid[slots[ix]])[0].tolist():
+            conv[k]._push()                              # host-side edits (if any) reach the device rows first
         eng = self.engine
         if self.problem_type == ProblemType.EIGENVALUE:
             blocks = {"v": np.abs(eng.d_gram(conv, POP_X, self.N_diag))}
@@ -663,8 +911,10 @@ class MAUS_Solver:
 
     def _update_global_diagnostics(self, iteration):
         C = SolutionCandidate.State
-        self._prefetch_converged()
-        gpos, gram = self._converged_gram()
+        view = self._pop_view()
+        st, slots, code = view
+        self._prefetch_converged(view)
+        gpos, gram = self._converged_gram(view)
         acc_pos, acc_key = [], []                          # Gram positions / lambda (sigma) of the accepted solutions
         total_active_candidates = len(self.candidates)
         sum_residuals = 0.0
@@ -675,64 +925,76 @@ class MAUS_Solver:
         current_sigma_magnitudes = []
         thr = self.strat_params["current_convergence_threshold"]
         max_s = None
-        for c in self.candidates:
-            if c.state == C.CONVERGED:
-                num_converged_all_types += 1
-                current_tuple = c.get_current_solution_params()
-                is_distinct = True
-                if current_tuple is None or any(p is None for p in current_tuple):
-                    continue
-                if self.problem_type == ProblemType.EIGENVALUE and gram is not None:
+        # the reference walks the whole population (AMS:429-462); only its CONVERGED members do more than add to two sums
+        for k in np.nonzero(code == _CONV)[0].tolist():
+            c = self.candidates[k]
+            num_converged_all_types += 1
+            current_tuple = c.get_current_solution_params()
+            is_distinct = True
+            if current_tuple is None or any(p is None for p in current_tuple):
+                continue
+            if self.problem_type == ProblemType.EIGENVALUE and gram is not None:
+                if acc_pos:
+                    s_lam = np.asarray(acc_key)
+                    close = np.abs(current_tuple[0] - s_lam) < (GLOBAL_LAMBDA_SIMILARITY_TOL + np.abs(s_lam) * 1e-6)
+                    if close.any() and (close & (gram["v"][gpos[id(c)], acc_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)).any():
+                        is_distinct = False
+            elif self.problem_type == ProblemType.EIGENVALUE:
+                for s_item in self.converged_solutions:
+                    s_lam, s_vec = s_item[0], s_item[1]
+                    effective_tol = GLOBAL_LAMBDA_SIMILARITY_TOL + np.abs(s_lam) * 1e-6
+                    if (np.abs(current_tuple[0] - s_lam) < effective_tol
+                            and np.abs(np.vdot(current_tuple[1], s_vec)) > GLOBAL_VECTOR_SIMILARITY_TOL):
+                        is_distinct = False
+                        break
+            elif self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
+                if (len(self.converged_solutions) > 0 and
+                        np.linalg.norm(current_tuple[0] - self.converged_solutions[0][0])
+                        < self.strat_params["convergence_tolerance"] * 100):
+                    is_distinct = False
+            elif self.problem_type == ProblemType.SVD:
+                if max_s is None:                  # AMS:444: the same value for every converged candidate of this pass
+                    sg = st.sig[slots]             # (sigma_k of every candidate, NaN where it is None)
+                    with np.errstate(invalid="ignore"):
+                        pos_sig = sg[sg > 0]
+                    max_s = pos_sig.max() if pos_sig.size else 1.0
+                if current_tuple[0].real / max_s < GLOBAL_SIGMA_SIMILARITY_TOL_REL:
+                    is_distinct = False
+                if is_distinct and gram is not None:
                     if acc_pos:
-                        s_lam = np.asarray(acc_key)
-                        close = np.abs(current_tuple[0] - s_lam) < (GLOBAL_LAMBDA_SIMILARITY_TOL + np.abs(s_lam) * 1e-6)
-                        if close.any() and (close & (gram["v"][gpos[id(c)], acc_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)).any():
+                        s_sig = np.asarray(acc_key)
+                        close = np.abs(current_tuple[0] - s_sig) < np.maximum(GLOBAL_SIGMA_SIMILARITY_TOL_ABS, s_sig * GLOBAL_SIGMA_SIMILARITY_TOL_REL)
+                        i = gpos[id(c)]
+                        if close.any() and (close & (gram["u"][i, acc_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)
+                                            & (gram["v"][i, acc_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)).any():
                             is_distinct = False
-                elif self.problem_type == ProblemType.EIGENVALUE:
+                elif is_distinct:
                     for s_item in self.converged_solutions:
-                        s_lam, s_vec = s_item[0], s_item[1]
-                        effective_tol = GLOBAL_LAMBDA_SIMILARITY_TOL + np.abs(s_lam) * 1e-6
-                        if (np.abs(current_tuple[0] - s_lam) < effective_tol
-                                and np.abs(np.vdot(current_tuple[1], s_vec)) > GLOBAL_VECTOR_SIMILARITY_TOL):
+                        s_sigma, s_u, s_v = s_item
+                        if (np.abs(current_tuple[0] - s_sigma) < max(GLOBAL_SIGMA_SIMILARITY_TOL_ABS, s_sigma * GLOBAL_SIGMA_SIMILARITY_TOL_REL)
+                                and np.abs(np.vdot(current_tuple[1], s_u)) > GLOBAL_VECTOR_SIMILARITY_TOL
+                                and np.abs(np.vdot(current_tuple[2], s_v)) > GLOBAL_VECTOR_SIMILARITY_TOL):
                             is_distinct = False
                             break
-                elif self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
-                    if (len(self.converged_solutions) > 0 and
-                            np.linalg.norm(current_tuple[0] - self.converged_solutions[0][0])
-                            < self.strat_params["convergence_tolerance"] * 100):
-                        is_distinct = False
-                elif self.problem_type == ProblemType.SVD:
-                    if max_s is None:                  # AMS:444: the same value for every converged candidate of this pass
-                        max_s = max((cand.sigma_k.real for cand in self.candidates
-                                     if cand.sigma_k is not None and cand.sigma_k.real > 0), default=1.0)
-                    if current_tuple[0].real / max_s < GLOBAL_SIGMA_SIMILARITY_TOL_REL:
-                        is_distinct = False
-                    if is_distinct and gram is not None:
-                        if acc_pos:
-                            s_sig = np.asarray(acc_key)
-                            close = np.abs(current_tuple[0] - s_sig) < np.maximum(GLOBAL_SIGMA_SIMILARITY_TOL_ABS, s_sig * GLOBAL_SIGMA_SIMILARITY_TOL_REL)
-                            i = gpos[id(c)]
-                            if close.any() and (close & (gram["u"][i, acc_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)
-                                                & (gram["v"][i, acc_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)).any():
-                                is_distinct = False
-                    elif is_distinct:
-                        for s_item in self.converged_solutions:
-                            s_sigma, s_u, s_v = s_item
-                            if (np.abs(current_tuple[0] - s_sigma) < max(GLOBAL_SIGMA_SIMILARITY_TOL_ABS, s_sigma * GLOBAL_SIGMA_SIMILARITY_TOL_REL)
-                                    and np.abs(np.vdot(current_tuple[1], s_u)) > GLOBAL_VECTOR_SIMILARITY_TOL
-                                    and np.abs(np.vdot(current_tuple[2], s_v)) > GLOBAL_VECTOR_SIMILARITY_TOL):
-                                is_distinct = False
-                                break
-                    current_sigma_magnitudes.append(current_tuple[0].real)
-                if is_distinct:
-                    self.converged_solutions.append(current_tuple)
-                    self.num_distinct_converged_solutions += 1
-                    if gram is not None:
-                        acc_pos.append(gpos[id(c)])
-                        acc_key.append(current_tuple[0])
-            if c.state not in (C.CONVERGED, C.RETIRED):
-                sum_residuals += c.residual_k if math.isfinite(c.residual_k) else (thr * 100)
-                sum_stuck_counters += c.stuck_counter
+                current_sigma_magnitudes.append(current_tuple[0].real)
+            if is_distinct:
+                self.converged_solutions.append(current_tuple)
+                self.num_distinct_converged_solutions += 1
+                if gram is not None:
+                    acc_pos.append(gpos[id(c)])
+                    acc_key.append(current_tuple[0])
+        # AMS:463-465 over the candidates that are neither CONVERGED nor RETIRED, summed in list order like the reference's
+        # loop (cumsum adds left to right; np.sum would add pairwise and round differently)
+        if st is not None:
+            act = (code != _CONV) & (code != _RETIRED)
+            if act.any():
+                asl = slots[act]
+                r = st.res[asl]
+                fin = np.isfinite(r)
+                total = np.cumsum(np.where(fin, r, thr * 100))[-1]
+                # (the sum is np.float64 once a residual -- np.float64 after a candidate's first step -- has been added)
+                sum_residuals = total if bool((fin & (st.res_kind[asl] != _F_PY)).any()) else float(total)
+                sum_stuck_counters = int(st.stuck[asl].sum())
         non_conv_retired_count = max(1, total_active_candidates - num_converged_all_types)
         self.avg_residual = sum_residuals / non_conv_retired_count
         self.avg_stuckness = sum_stuck_counters / non_conv_retired_count
@@ -787,70 +1049,81 @@ class MAUS_Solver:
     # ---- AMS:504-549 ------------------------------------------------------------------------------
     def _manage_candidates(self, iteration):
         C = SolutionCandidate.State
+        view = self._pop_view()
+        st, slots, code = view
+        cl = self.candidates
         survivors = []
-        # sorted(key=lambda x: (-x.w_k, x.residual_k if isfinite else inf)), AMS:506, with the keys built on arrays (the
-        # per-candidate np.isfinite of the lambda was 9 ms per loop body at 6144 candidates); same tuples, same stable sort
-        res_key = np.array([c.residual_k for c in self.candidates], dtype=np.float64)
-        res_key = np.where(np.isfinite(res_key), res_key, np.inf).tolist()
-        keys = [(-c.w_k, r) for c, r in zip(self.candidates, res_key)]
-        sorted_candidates = [self.candidates[k] for k in sorted(range(len(keys)), key=keys.__getitem__)]
-        tol = self.strat_params["convergence_tolerance"]
-        self._prefetch_converged()
-        gpos, gram = self._converged_gram()
-        sur_pos, sur_key = [], []                          # Gram positions / lambda (sigma) of the converged survivors
-        for c in sorted_candidates:
-            redundant = False
-            if c.state == C.CONVERGED and gram is not None:
-                tc = c.get_current_solution_params()
-                if sur_pos and not (tc is None or any(p is None for p in tc)):
-                    i = gpos[id(c)]
-                    key = np.asarray(sur_key)
-                    if self.problem_type == ProblemType.EIGENVALUE:
-                        close = np.abs(tc[0] - key) < (GLOBAL_LAMBDA_SIMILARITY_TOL + np.abs(key) * 1e-6)
-                        redundant = bool(close.any() and (close & (gram["v"][i, sur_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)).any())
-                    else:
-                        live = ~(key.real < GLOBAL_SIGMA_SIMILARITY_TOL_ABS / 100)
-                        close = np.abs(tc[0] - key) < np.maximum(GLOBAL_SIGMA_SIMILARITY_TOL_ABS, key * GLOBAL_SIGMA_SIMILARITY_TOL_REL)
-                        redundant = bool((live & close & (gram["u"][i, sur_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)
-                                          & (gram["v"][i, sur_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)).any())
-            elif c.state == C.CONVERGED:
-                for s_c in survivors:
-                    if s_c.state != C.CONVERGED:
-                        continue
-                    tc, ts = c.get_current_solution_params(), s_c.get_current_solution_params()
-                    if tc is None or ts is None or any(p is None for p in tc) or any(p is None for p in ts):
-                        continue
-                    if self.problem_type == ProblemType.EIGENVALUE:
-                        if (np.abs(tc[0] - ts[0]) < (GLOBAL_LAMBDA_SIMILARITY_TOL + np.abs(ts[0]) * 1e-6)
-                                and np.abs(np.vdot(tc[1], ts[1])) > GLOBAL_VECTOR_SIMILARITY_TOL):
-                            redundant = True
-                            break
-                    elif self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
-                        if np.linalg.norm(tc[0] - ts[0]) < tol * 10:
-                            redundant = True
-                            break
-                    elif self.problem_type == ProblemType.SVD:
-                        if ts[0].real < GLOBAL_SIGMA_SIMILARITY_TOL_ABS / 100:
-                            redundant = False
-                        elif (np.abs(tc[0] - ts[0]) < max(GLOBAL_SIGMA_SIMILARITY_TOL_ABS, ts[0] * GLOBAL_SIGMA_SIMILARITY_TOL_REL)
-                              and np.abs(np.vdot(tc[1], ts[1])) > GLOBAL_VECTOR_SIMILARITY_TOL
-                              and np.abs(np.vdot(tc[2], ts[2])) > GLOBAL_VECTOR_SIMILARITY_TOL):
-                            redundant = True
-                            break
-            if redundant:
-                c.state = C.RETIRED
-            elif c.state == C.RETIRED:
-                pass
-            elif ((c.w_k < self.strat_params["min_survival_weight"] and c.state != C.CONVERGED)
-                  or (c.stuck_counter >= GLOBAL_MAX_STUCK_FOR_RETIREMENT and c.state != C.CONVERGED)):
-                c.state = C.RETIRED
-            else:
-                survivors.append(c)
-                if gram is not None and c.state == C.CONVERGED:
-                    ts = c.get_current_solution_params()
-                    if not (ts is None or any(p is None for p in ts)):
-                        sur_pos.append(gpos[id(c)])
-                        sur_key.append(ts[0])
+        if st is not None:
+            # sorted(key=lambda x: (-x.w_k, x.residual_k if isfinite else inf)), AMS:506: the same stable order from a
+            # lexicographic sort of the two key arrays (the per-candidate key tuples were 5 ms per loop body at 6144 candidates)
+            res_key = st.res[slots]
+            res_key = np.where(np.isfinite(res_key), res_key, np.inf)
+            order = np.lexsort((res_key, -st.w[slots]))
+            tol = self.strat_params["convergence_tolerance"]
+            self._prefetch_converged(view)
+            gpos, gram = self._converged_gram(view)
+            sur_pos, sur_key = [], []                          # Gram positions / lambda (sigma) of the converged survivors
+            conv_survivors = []
+            scode = code[order]
+            sslots = slots[order]
+            retire = np.zeros(len(cl), dtype=bool)             # in sorted order
+            # AMS:507-527 only does something for CONVERGED candidates: the greedy redundancy test against the converged
+            # survivors in front of them
+            for pos in np.nonzero(scode == _CONV)[0].tolist():
+                c = cl[order[pos]]
+                redundant = False
+                if gram is not None:
+                    tc = c.get_current_solution_params()
+                    if sur_pos and not (tc is None or any(p is None for p in tc)):
+                        i = gpos[id(c)]
+                        key = np.asarray(sur_key)
+                        if self.problem_type == ProblemType.EIGENVALUE:
+                            close = np.abs(tc[0] - key) < (GLOBAL_LAMBDA_SIMILARITY_TOL + np.abs(key) * 1e-6)
+                            redundant = bool(close.any() and (close & (gram["v"][i, sur_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)).any())
+                        else:
+                            live = ~(key.real < GLOBAL_SIGMA_SIMILARITY_TOL_ABS / 100)
+                            close = np.abs(tc[0] - key) < np.maximum(GLOBAL_SIGMA_SIMILARITY_TOL_ABS, key * GLOBAL_SIGMA_SIMILARITY_TOL_REL)
+                            redundant = bool((live & close & (gram["u"][i, sur_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)
+                                              & (gram["v"][i, sur_pos] > GLOBAL_VECTOR_SIMILARITY_TOL)).any())
+                else:
+                    for s_c in conv_survivors:
+                        tc, ts = c.get_current_solution_params(), s_c.get_current_solution_params()
+                        if tc is None or ts is None or any(p is None for p in tc) or any(p is None for p in ts):
+                            continue
+                        if self.problem_type == ProblemType.EIGENVALUE:
+                            if (np.abs(tc[0] - ts[0]) < (GLOBAL_LAMBDA_SIMILARITY_TOL + np.abs(ts[0]) * 1e-6)
+                                    and np.abs(np.vdot(tc[1], ts[1])) > GLOBAL_VECTOR_SIMILARITY_TOL):
+                                redundant = True
+                                break
+                        elif self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
+                            if np.linalg.norm(tc[0] - ts[0]) < tol * 10:
+                                redundant = True
+                                break
+                        elif self.problem_type == ProblemType.SVD:
+                            if ts[0].real < GLOBAL_SIGMA_SIMILARITY_TOL_ABS / 100:
+                                redundant = False
+                            elif (np.abs(tc[0] - ts[0]) < max(GLOBAL_SIGMA_SIMILARITY_TOL_ABS, ts[0] * GLOBAL_SIGMA_SIMILARITY_TOL_REL)
+                                  and np.abs(np.vdot(tc[1], ts[1])) > GLOBAL_VECTOR_SIMILARITY_TOL
+                                  and np.abs(np.vdot(tc[2], ts[2])) > GLOBAL_VECTOR_SIMILARITY_TOL):
+                                redundant = True
+                                break
+                if redundant:
+                    retire[pos] = True
+                else:
+                    conv_survivors.append(c)
+                    if gram is not None:
+                        ts = c.get_current_solution_params()
+                        if not (ts is None or any(p is None for p in ts)):
+                            sur_pos.append(gpos[id(c)])
+                            sur_key.append(ts[0])
+            # AMS:528-531 for everybody else: weight below the survival threshold or stuck for too long
+            other = (scode != _CONV) & (scode != _RETIRED)
+            retire |= other & ((st.w[sslots] < self.strat_params["min_survival_weight"])
+                               | (st.stuck[sslots] >= GLOBAL_MAX_STUCK_FOR_RETIREMENT))
+            st.state[sslots[retire]] = _RETIRED
+            keep = ~retire & (scode != _RETIRED)
+            survivors = [cl[k] for k in order[keep].tolist()]
+            self._view_cache = (survivors, sslots[keep])
         self.candidates = survivors
         target = self.N_diag
         if self.problem_type == ProblemType.SOLVE_LINEAR_SYSTEM:
@@ -878,13 +1151,19 @@ class MAUS_Solver:
             new_candidate = self._new_candidate(**kw, initial_weight=0.01)
             new_candidate.alpha_local_step = GLOBAL_DEFAULT_ALPHA_V_INITIAL * (1 + self.strat_params["overall_psi_aggression_factor"] / 10.0)
             self.candidates.append(new_candidate)
+        cache = self.__dict__.get("_view_cache")
+        if cache is not None and cache[0] is self.candidates and len(cache[1]) < len(self.candidates):
+            born = np.asarray([c._slot for c in self.candidates[len(cache[1]):]], dtype=np.int64)
+            self._view_cache = (self.candidates, np.concatenate([cache[1], born]))
 
     # ---- the loop body AMS:573-577 ------------------------------------------------------------------
     def step_population(self):
         """The hot loop `for candidate in self.candidates: update_solution_step(...)`, batched."""
         C = SolutionCandidate.State
-        active = [c for c in self.candidates if c.state not in (C.CONVERGED, C.RETIRED)]
-        self.engine.step(active, self.M, self.b, self.strat_params, self.problem_knowledge)
+        st, slots, code = self._pop_view()
+        ix = np.nonzero((code != _CONV) & (code != _RETIRED))[0]
+        active = [self.candidates[k] for k in ix.tolist()]
+        self.engine.step(active, self.M, self.b, self.strat_params, self.problem_knowledge, slots[ix])
         self.candidate_steps += len(active)
         return len(active)
 

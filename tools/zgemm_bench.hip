@@ -6,10 +6,17 @@
 //   tools/bin/zgemm_bench M N K ld batch [iters] [zero] [shared]
 //       zero    all-zero operands (clock check: the chip holds a higher clock on zeros)
 //       shared  every matrix reads the same A and B (traffic check)
+//       lu      the LU's own operand form: tile-major H / U arrays of npad = M + K rows (luws.h), A and C rows through a row list
+//               (identity; `perm`: a random permutation of the rows below K, as implicit pivoting leaves them)
 // Prints ms per launch and 8MNK-equivalent TFLOP/s.  The kernels come straight from the library's translation unit.
 #include "../adaptive_matrix_solver_amd/csrc/zgemm.hip"
 #include <cstdio>
 #include <cstring>
+#include <vector>
+#include <numeric>
+#include <algorithm>
+#include <random>
+#include "../adaptive_matrix_solver_amd/csrc/luws.h"
 
 __global__ void fill_rand_kernel(double* p, size_t n, unsigned seed) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
@@ -22,8 +29,43 @@ int main(int argc, char** argv) {
     if (argc < 6) { fprintf(stderr, "usage: %s M N K ld batch [iters] [zero] [shared]\n", argv[0]); return 2; }
     const int M = atoi(argv[1]), N = atoi(argv[2]), K = atoi(argv[3]), ld = atoi(argv[4]), batch = atoi(argv[5]);
     const int iters = argc > 6 ? atoi(argv[6]) : 5;
-    bool zero = false, shared = false;
-    for (int i = 7; i < argc; ++i) { zero |= !strcmp(argv[i], "zero"); shared |= !strcmp(argv[i], "shared"); }
+    bool zero = false, shared = false, lu = false, permute = false;
+    for (int i = 7; i < argc; ++i) { zero |= !strcmp(argv[i], "zero"); shared |= !strcmp(argv[i], "shared"); lu |= !strcmp(argv[i], "lu"); permute |= !strcmp(argv[i], "perm"); }
+    if (lu) {
+        // H[rows[m]][K + n] -= H[rows[m]][k] * U[k][K + n]: the first trailing update of a matrix of npad = M + K rows, N <= M + 32
+        const int npad = M + K;
+        if (N > M + 32 || (npad % 64)) { fprintf(stderr, "lu mode: N <= M + 32, M + K a multiple of 64\n"); return 2; }
+        const long strideH = (long)npad * lu_ntiles(npad) * LU_TW;
+        c128 *H = nullptr, *U = nullptr; int* rows = nullptr;
+        CK(hipMalloc((void**)&H, sizeof(c128) * strideH * batch));
+        CK(hipMalloc((void**)&U, sizeof(c128) * strideH * batch));
+        CK(hipMalloc((void**)&rows, sizeof(int) * (size_t)npad * batch));
+        hipStream_t st; CK(hipStreamCreate(&st));
+        hipLaunchKernelGGL(fill_rand_kernel, dim3(2048), dim3(256), 0, st, (double*)H, (size_t)strideH * batch * 2, 12345u);
+        hipLaunchKernelGGL(fill_rand_kernel, dim3(2048), dim3(256), 0, st, (double*)U, (size_t)strideH * batch * 2, 777u);
+        std::vector<int> hr((size_t)npad * batch);
+        std::mt19937 gen(1);
+        for (int g = 0; g < batch; ++g) {
+            int* r = hr.data() + (size_t)g * npad;
+            std::iota(r, r + npad, 0);
+            if (permute) std::shuffle(r, r + npad, gen);      // after K pivot steps the remaining rows are anywhere
+        }
+        CK(hipMemcpy(rows, hr.data(), sizeof(int) * hr.size(), hipMemcpyHostToDevice));
+        auto launch = [&]() { maus_zgemm_launch_lu(st, M, N, K, H, U, H, npad, strideH, 0, 0, K, batch, rows + K, npad); };
+        launch();
+        CK(hipStreamSynchronize(st));
+        hipEvent_t t0, t1; CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
+        CK(hipEventRecord(t0, st));
+        for (int i = 0; i < iters; ++i) launch();
+        CK(hipEventRecord(t1, st));
+        CK(hipEventSynchronize(t1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, t0, t1));
+        ms /= iters;
+        CK(hipGetLastError());
+        printf("M=%d N=%d K=%d npad=%d batch=%d lu%s: %.3f ms per launch, %.1f TFLOP/s (8MNK)\n", M, N, K, npad, batch, permute ? " perm" : "",
+               ms, 8.0 * M * N * K * batch / (ms * 1e-3) / 1e12);
+        return 0;
+    }
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || iters <= 0 || ld < (N > K ? N : K) + K) { fprintf(stderr, "bad sizes\n"); return 2; }
     const size_t per = (size_t)((long)M + K) * ld;
     c128* base = nullptr;
