@@ -872,7 +872,8 @@ class DeviceEngine:
         self._pre_resid = {}
         while i < len(cands):
             run = cands[i:]
-            slots = [c._slot for c in run]
+            slots = self._slots(run)
+            st = self.store
             # Sharded run, direct solver, stream-independent host side ('mt19937' / 'none'): this rank's share of the WHOLE step --
             # Rayleigh quotient, shifted solve, relaxed update, residual -- before anything is exchanged, then one 64-byte record
             # per candidate.  Accepted if no candidate of the run takes an exceptional branch (the common case by far);
@@ -904,14 +905,15 @@ class DeviceEngine:
                         lam[k] = complex(0.0, 0.0)
                     else:
                         lam[k] = num[k] / den[k]
-                for k, c in enumerate(run):
-                    c.lambda_k = lam[k]
+                st.lam[slots] = lam                                     # lambda_k = the np.complex128 quotient
+                st.lam_kind[slots] = C_NP
+                st.lam_obj[slots] = MISSING
                 shift = lam
             else:
                 shift = np.zeros(len(run), dtype=np.complex128)
 
             # --- first attempt of every candidate, batched (attempt 0, preferred method) ---
-            stuck = np.array([c.stuck_counter for c in run])
+            stuck = st.stuck[slots]
             psi0 = np.array([(base_psi * (10 ** (0 / 2.0)) * (10 ** (s / 3.0))).real for s in stuck])   # AMS:44
             first_method = pref
             rng_after = None
@@ -964,11 +966,14 @@ class DeviceEngine:
             # --- relaxed update of the good prefix (AMS:280-286) ---
             e4 = None
             if nb > 0:
-                alpha = np.array([complex(c.alpha_local_step) for c in run[:nb]], dtype=np.complex128)
+                if (st.alpha_kind[slots[:nb]] == EXACT).any():          # an alpha of a type some caller assigned
+                    alpha = np.array([complex(c.alpha_local_step) for c in run[:nb]], dtype=np.complex128)
+                else:
+                    alpha = st.alpha[slots[:nb]].astype(np.complex128)
                 if is_eig and pert == PERT_MT19937:
                     # device-side snapshot of the run's vectors (POP_U is unused by eig problems): an E4 event moves the
                     # draws of everybody behind it, and their speculative update must then be undone
-                    self.ctx.pop_copy(POP_U, POP_X, [c._slot for c in run[:nb]])
+                    self.ctx.pop_copy(POP_U, POP_X, slots[:nb])
                 nrm = self.d_relax(run[:nb], alpha, is_eig)
                 if is_eig:
                     tiny = np.nonzero(~(nrm > 1e-10))[0]
@@ -985,18 +990,23 @@ class DeviceEngine:
             if pert == PERT_UNIFORM:
                 np.random.set_state(rng_after[nvalid - 1] if nvalid > 0 else rng_start)
             pending_words = 0          # E3 consumption not yet applied to the stream (one jump per run)
-            for k in range(nvalid):
-                c = run[k]
-                if pert != PERT_UNIFORM and not clean:
-                    pending_words += per_cand_words * (2 if fb[k] else 1)   # E3 (attempt 0, and its direct-solver retry)
-                c.local_psi_retries_needed = 0                          # attempts == 0 (AMS:278)
-                c._invalidate()
-                if is_eig and e4 is not None and (k == e4 or (pert != PERT_UNIFORM and not (nrm[k] > 1e-10))):
-                    _advance_numpy_stream(pending_words)
-                    pending_words = 0
-                    c.v_k = (np.random.rand(n) + 1j * np.random.rand(n)) / np.sqrt(n)     # E4 (AMS:283)
-                    c._push(force=True)
-                c.stuck_counter = max(0, c.stuck_counter - 1)           # AMS:286
+            vs = slots[:nvalid]
+            st.retries[vs] = 0                                          # attempts == 0 (AMS:278)
+            st.host_valid[vs] = False                                   # _invalidate(): the device rows are the new state
+            st.dev_valid[vs] = True
+            if is_eig and e4 is not None:
+                for k in range(nvalid):
+                    c = run[k]
+                    if pert != PERT_UNIFORM and not clean:
+                        pending_words += per_cand_words * (2 if fb[k] else 1)   # E3 (attempt 0, and its direct-solver retry)
+                    if k == e4 or (pert != PERT_UNIFORM and not (nrm[k] > 1e-10)):
+                        _advance_numpy_stream(pending_words)
+                        pending_words = 0
+                        c.v_k = (np.random.rand(n) + 1j * np.random.rand(n)) / np.sqrt(n)     # E4 (AMS:283)
+                        c._push(force=True)
+            elif pert != PERT_UNIFORM and not clean:
+                pending_words = per_cand_words * (nvalid + int(fb[:nvalid].sum()))      # E3 of every accepted candidate
+            st.stuck[vs] = np.maximum(st.stuck[vs] - 1, 0)              # AMS:286
             if clean:
                 ahead.apply()                                           # whole run's E3 consumption, precomputed
             else:
@@ -1005,7 +1015,7 @@ class DeviceEngine:
                 for c in run[nvalid:nb]:                                # speculative relax undone
                     c._restore_device()
             if pert == PERT_MT19937 and nvalid < nb:
-                self.ctx.pop_copy(POP_X, POP_U, [c._slot for c in run[nvalid:nb]])
+                self.ctx.pop_copy(POP_X, POP_U, slots[nvalid:nb])
             i += nvalid
             if nvalid == nb and nb < len(run):
                 # --- the candidate whose first attempt failed: exact sequential ladder ---

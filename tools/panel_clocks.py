@@ -13,6 +13,9 @@ import scenarios  # noqa: E402
 from adaptive_matrix_solver_amd import Context, _cabi  # noqa: E402
 from adaptive_matrix_solver_amd._cabi import PERT_MT19937  # noqa: E402
 
+if os.environ.get("MAUS_LIB"):                               # the -DMAUS_PANEL_CLOCK build kept beside the shipped library
+    _cabi.LIB_PATH = os.environ["MAUS_LIB"]
+
 n = int(os.environ.get("LU_N", 4096))
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 A = scenarios.ginibre(n, n)
