@@ -821,7 +821,7 @@ int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double
         // they run at ~5 TB/s, the zgemm beside them loses more than they gain, and whole driver-shaped runs give 352 / 338
         // candidate-steps/s with 1 / 2 streams (profiles/r03_streams_fixed.txt) -- the tuner, which picked three from one
         // noisy sample per count, is gone.  Results do not depend on the split (tests/test_gpu_bench_path.py: bit-equal).
-        constexpr int min_sub = 64;                 // smallest sub-batch that gets a stream of its own
+        constexpr int min_sub = 64;                 // smallest sub-batch that gets a stream of its own (round 4, 16 / 32 / 64 solves split into sub-batches of 8-32 on 2-4 streams: 3-30 % slower, profiles/r04_small_batch_streams_negative.txt)
         const int S = std::max(1, std::min(nst, G / min_sub));
         // One more pass without the multi-workgroup panel if a rendezvous of it timed out (info = INT_MIN): its premise --
         // all workgroups of a matrix resident at once -- does not hold on a device that somebody else is using too.  The
