@@ -5,9 +5,11 @@
 // (LAPACK zheevr: zhetrd -> dstemr -> zunmtr; one decomposition per matrix here), which at n = 8192 costs 73 s
 // on the GPU box's host against 7 ms per loop body on the device:
 //   1. maus_herm_tridiag        A = Q T Q^H, zhetrd('L') semantics: blocked Householder tridiagonalisation, zlatrd panels of
-//                               64 columns + a rank-128 update of the trailing matrix per panel (one zgemm: [V W][W V]^H).
+//                               64 columns + a rank-128 update of the trailing matrix per panel ([V W][W V]^H on the zgemm).
 //                               Half of the 16/3 n^3 flops are Hermitian matrix-vector products with the trailing matrix --
-//                               HBM-bound, 16/3 n^3 bytes with full storage -- the other half the MFMA zgemm.
+//                               HBM-bound: 8/3 n^3 bytes since round 4, when the matvec, the update and everything else began
+//                               to touch the lower triangle only (16/3 n^3 with the full storage of rounds 2-3) -- the other
+//                               half the MFMA zgemm.
 //   2. maus_herm_tridiag_eig    the real symmetric tridiagonal eigenproblem, O(n^2) per sweep: bisection on the Sturm count and
 //                               eigenvectors from the twisted factorisation, one thread per eigenpair; the caller
 //                               (engine.device_eigh) falls back to scipy.linalg.eigh_tridiagonal (LAPACK dstemr, the kernel
@@ -26,10 +28,11 @@
 //   col1   a(i:n,i) -= V(i:n,0:j) conj(W(i,0:j)) + W(i:n,0:j) conj(V(i,0:j))            (row-parallel; partial |.|^2; d(i))
 //   col2   every workgroup repeats zlarfg's scalar part from the partials in fixed order (beta / tau / scale; workgroup 0 keeps
 //          e(i), tau(i)) and forms v = scale * a on the fly; then, by workgroup index,
-//            hemv:  w0 = A22 v for four rows, v -> panel column j and the reflector store, partial w0^H v
+//            hemv:  partial vectors of w0 = A22 v from up to eight 64 x 64 tiles of the LOWER triangle (each tile serves its rows
+//                   and its columns), v -> panel column j and the reflector store, partial w0^H v
 //                   (A22 = the trailing matrix as the previous panels left it: this panel's reflectors come in below)
 //            dots:  t1 = W(:,0:j)^H v, t2 = V(:,0:j)^H v, one column each
-//   col3   u = w0 - V t1 - W t2,  w = tau u + alpha v  -> panel column j of W,  alpha = -1/2 tau (w^H v) with
+//   col3   w0 from the partial vectors; u = w0 - V t1 - W t2,  w = tau u + alpha v  -> panel column j of W,  alpha = -1/2 tau (w^H v) with
 //          w^H v = conj(tau) (w0^H v - 2 Re sum_k conj(t1_k) t2_k)  from the partials and the dots: no second pass over w;
 //          rows <= i of a panel column are neither written nor read
 // All reductions run in a fixed order (no atomics), so a decomposition is reproducible bit for bit.  The host keeps at most two
@@ -122,18 +125,80 @@ __device__ __forceinline__ Larfg herm_larfg_scalars(const c128* __restrict__ col
     return L;
 }
 
-// Workgroups [0, nh): w0[r] = sum_{c > i} Aw[r][c] v[c] for r > i, one wave per row, four rows per workgroup; v -> PV[j], VQ[i]
-// (zeros above, 1 at i+1); cpart[b] = sum over the workgroup's rows of conj(w0_r) v_r.
-// Workgroups [nh, nh + 2j): t[k] = W_k^H v (k < j), t[j + k] = V_k^H v over the rows > i.
-__global__ void __launch_bounds__(256)
-herm_col2_kernel(const c128* __restrict__ Aw, int n, int i, int j, int nh, const c128* __restrict__ col, const double* __restrict__ part,
+// The Hermitian matvec w0 = A22 v reads the LOWER triangle only (round 4; rounds 2-3 read full rows of a matrix kept in both
+// triangles: 16/3 n^3 bytes over the reduction, 543 of its 710 ms at n = 8192).  The trailing matrix is cut into 64 x 64 tiles
+// on the absolute grid; a tile (bi, bj), bi >= bj, serves its rows (u_R += A[R][c] v_c) and its columns (z_c += conj(A[R][c]) v_R),
+// the diagonal tile with its lower part only and a real diagonal (zhemv 'L').  A workgroup of eight waves takes up to hch tiles (4 .. 16, chosen per column)
+// of one block row; wave w owns the columns 8 w .. 8 w + 7 of every tile and all 64 rows (a load instruction = eight rows x one
+// 128-byte line), so the column sums z are complete inside the wave -- a register sum over the eight loads, then over the
+// eight row-lanes -- and leave per tile without a barrier; the row sums u stay in registers over the whole chunk and cross
+// the waves once at its end.  Nothing is accumulated across workgroups: the partial vectors go to PU[chunk][row] and
+// PZ[block row][column], and col3 adds them in a fixed order,  w0_r = sum_ch PU[ch][r] + sum_{bi >= block(r)} PZ[bi][r]
+// (6 % of the tile traffic).
+// (Measured on the way: one wave per tile with lane = column and a DPP reduction per row, 653 ms of col2 at n = 8192; eight-row
+// slices per wave with an LDS exchange and two barriers per tile, 488 ms.)
+// Workgroups [0, ns): the tiles; also v -> PV[j], VQ[i] (first chunk of a block row) and cpart[b] = sum conj(partial) v over
+// the workgroup's partials (w0^H v is linear in them).
+// Workgroups [ns, ns + 2j): t[k] = W_k^H v (k < j), t[j + k] = V_k^H v over the rows > i.
+constexpr int HTB = 64;        // tile edge
+constexpr int HCH_MIN = 4, HCH_MAX = 16;   // tiles per workgroup: chosen per column so that the launch has ~3 workgroups per CU
+constexpr int HW2 = 8;         // waves of a col2 workgroup
+
+#define MAUS_DPP_F64(V, CTRL) __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(V), CTRL, 0xf, 0xf, false), \
+                                               __builtin_amdgcn_update_dpp(0, __double2loint(V), CTRL, 0xf, 0xf, false))
+// sum over the eight lanes that differ in the low three bits of the lane number; every one of them gets it
+__device__ __forceinline__ double sum_low8(double v) {
+    v += MAUS_DPP_F64(v, 0xB1);            // quad_perm [1,0,3,2]
+    v += MAUS_DPP_F64(v, 0x4E);            // quad_perm [2,3,0,1]
+    v += MAUS_DPP_F64(v, 0x141);           // row_half_mirror: the other quad of the eight
+    return v;
+}
+// sum over the eight lanes l, l + 8, .., l + 56 (l < 8), valid in lanes 0..7: the two halves of a 16-lane row by a rotation,
+// the four rows through the permute network in a fixed order
+__device__ __forceinline__ double sum_stride8(double v) {
+    v += MAUS_DPP_F64(v, 0x128);           // row_ror:8
+    v += __shfl_down(v, 32, 64);
+    v += __shfl_down(v, 16, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(64 * HW2, 4)
+herm_col2_kernel(const c128* __restrict__ Aw, int n, int i, int j, int ns, int hch, const c128* __restrict__ col, const double* __restrict__ part,
                  int nparts, c128* __restrict__ PV, const c128* __restrict__ PW, c128* __restrict__ VQ, c128* __restrict__ tau,
-                 double* __restrict__ e, c128* __restrict__ w0, c128* __restrict__ cpart, c128* __restrict__ t)
+                 double* __restrict__ e, c128* __restrict__ PU, c128* __restrict__ PZ, c128* __restrict__ cpart, c128* __restrict__ t)
 {
     __shared__ c128 s_scal;
-    __shared__ double sbuf[4];
-    __shared__ c128 s_dot[4];
+    __shared__ double sbuf[HW2];
+    __shared__ c128 s_dot[HW2];
+    __shared__ c128 s_v[HTB];
+    __shared__ c128 s_u[HW2][HTB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const c128 zero = cmake(0.0, 0.0);
+    // (block row, chunk) of a tile workgroup: block row b0 + tb has tb / hch + 1 chunks of hch tiles
+    const int b0 = (i + 1) / HTB;
+    int bi = 0, ch = 0, bj0 = 0, bj1 = -1;
+    if (b < ns) {
+        int tb = 0, base = 0;
+        for (;;) { const int nc = tb / hch + 1; if (b < base + nc) break; base += nc; ++tb; }
+        ch = b - base; bi = b0 + tb;
+        bj0 = b0 + ch * hch; bj1 = min(bi, bj0 + hch - 1);
+    }
+    const int r0 = bi * HTB;
+    const int rr = lane >> 3, cc = lane & 7;                              // row inside a group of eight, column inside the wave's eight
+    // 32 rows of a slice at a time: four loads in a lane's registers, the next four in flight
+    c128 a[4];
+    auto load = [&](int bj, int half, c128 (&x)[4]) {                     // rows 32 half .. + 31 of this wave's 64 x 8 slice of tile (bi, bj)
+        const int c = bj * HTB + 8 * wave + cc;
+        const bool cok = c > i && c < n;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int R = r0 + 32 * half + 8 * k + rr;
+            x[k] = (cok && R > i && R < n) ? Aw[(long)R * n + c] : zero;
+        }
+    };
+    // the first rows are requested before the scalars below exist: they do not depend on them
+    if (bj0 <= bj1) load(bj0, 0, a);
     if (wave == 0) {
         // the |.|^2 partials of col1 in a fixed order: lane-strided, then the butterfly -- the same bits in every workgroup
         double ss = 0.0;
@@ -145,57 +210,112 @@ herm_col2_kernel(const c128* __restrict__ Aw, int n, int i, int j, int nh, const
             if (blockIdx.x == 0) { tau[i] = L.tau; e[i] = L.beta; }
         }
     }
-    __syncthreads();
+    lds_barrier();
     const c128 scal = s_scal;
     auto vat = [&](int c) { return (c == i + 1) ? cmake(1.0, 0.0) : cmul(col[c], scal); };     // c > i
-    const int b = blockIdx.x;
-    if (b < nh) {
-        const int r = i + 1 + b * 4 + wave;
-        c128 dot = cmake(0.0, 0.0);
-        if (r < n) {
-            const c128* row = Aw + (long)r * n;
-            c128 s0 = cmake(0.0, 0.0), s1 = s0, s2 = s0, s3 = s0;
-            int c = i + 1 + lane;
-            for (; c + 192 < n; c += 256) {
-                cfma(s0, row[c], vat(c)); cfma(s1, row[c + 64], vat(c + 64)); cfma(s2, row[c + 128], vat(c + 128)); cfma(s3, row[c + 192], vat(c + 192));
+    if (b < ns) {
+        if (tid < HTB) {
+            const int R = r0 + tid;
+            const bool on = R > i && R < n;
+            const c128 v = on ? vat(R) : zero;
+            s_v[tid] = v;
+            if (ch == 0 && on) { PV[(long)j * n + R] = v; VQ[(long)i * n + R] = v; }
+        }
+        lds_barrier();
+        c128 acc0[4], acc1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc0[k] = acc1[k] = zero;
+        c128 zdot = zero;
+        for (int bj = bj0; bj <= bj1; ++bj) {
+            const int c = bj * HTB + 8 * wave + cc;
+            const bool cok = c > i && c < n;
+            const c128 vc = cok ? vat(c) : zero;
+            const bool diag = bj == bi;
+            c128 zc = zero;
+            auto half = [&](int h, c128 (&acc)[4]) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int rl = 32 * h + 8 * k + rr, R = r0 + rl;
+                    c128 x = a[k];
+                    if (diag) {
+                        if (R == c) x.y = 0.0;
+                        if (R >= c) cfma(acc[k], x, vc);
+                        if (R > c) cfma_conj(zc, x, s_v[rl]);
+                    } else {
+                        cfma(acc[k], x, vc);
+                        cfma_conj(zc, x, s_v[rl]);
+                    }
+                }
+            };
+            c128 an[4];
+            load(bj, 1, an);
+            half(0, acc0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = an[k];
+            if (bj < bj1) load(bj + 1, 0, an);
+            half(1, acc1);
+            if (bj < bj1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = an[k];
             }
-            for (; c < n; c += 64) cfma(s0, row[c], vat(c));
-            const double sr = wave_sum((s0.x + s1.x) + (s2.x + s3.x)), si = wave_sum((s0.y + s1.y) + (s2.y + s3.y));
-            if (lane == 0) {
-                const c128 wr = cmake(sr, si), vr = vat(r);
-                w0[r] = wr;
-                PV[(long)j * n + r] = vr; VQ[(long)i * n + r] = vr;
-                cfma_conj(dot, wr, vr);
+            const c128 z = cmake(sum_stride8(zc.x), sum_stride8(zc.y));   // lanes 0..7: the column sums of this wave's columns
+            if (lane < 8) {
+                if (c < n) PZ[(long)bi * n + c] = z;
+                cfma_conj(zdot, z, vc);                                    // vc = 0 where the column is not part of the matvec
             }
         }
-        if (lane == 0) s_dot[wave] = dot;
-        __syncthreads();
-        if (tid == 0) cpart[b] = cadd(cadd(s_dot[0], s_dot[1]), cadd(s_dot[2], s_dot[3]));
+        // the row sums: over the wave's eight columns on the DPP network, over the waves through LDS
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double sr0 = sum_low8(acc0[k].x), si0 = sum_low8(acc0[k].y), sr1 = sum_low8(acc1[k].x), si1 = sum_low8(acc1[k].y);
+            if (cc == 0) { s_u[wave][8 * k + rr] = cmake(sr0, si0); s_u[wave][32 + 8 * k + rr] = cmake(sr1, si1); }
+        }
+        const double zr = wave_sum(lane < 8 ? zdot.x : 0.0), zi = wave_sum(lane < 8 ? zdot.y : 0.0);
+        if (lane == 0) s_dot[wave] = cmake(zr, zi);
+        lds_barrier();
+        if (wave == 0) {
+            c128 u = s_u[0][lane];
+#pragma unroll
+            for (int q = 1; q < HW2; ++q) u = cadd(u, s_u[q][lane]);
+            const int R = r0 + lane;
+            if (R < n) PU[(long)ch * n + R] = u;
+            c128 d = zero;
+            cfma_conj(d, u, s_v[lane]);                                    // s_v = 0 on the rows that are not part of the matvec
+            const double dr = wave_sum(d.x), di = wave_sum(d.y);
+            if (lane == 0) {
+                c128 dsum = cmake(dr, di);
+                for (int q = 0; q < HW2; ++q) dsum = cadd(dsum, s_dot[q]);
+                cpart[b] = dsum;
+            }
+        }
     } else {
-        const int k = b - nh;
+        const int k = b - ns;
         const c128* p = (k < j) ? PW + (long)k * n : PV + (long)(k - j) * n;
         c128 s = cmake(0.0, 0.0);
-        for (int r = i + 1 + tid; r < n; r += 256) cfma_conj(s, p[r], vat(r));
+        for (int r = i + 1 + tid; r < n; r += 64 * HW2) cfma_conj(s, p[r], vat(r));
         const double sr = block_sum_d(s.x, sbuf), si = block_sum_d(s.y, sbuf);
         if (tid == 0) t[k] = cmake(sr, si);
     }
 }
+#undef MAUS_DPP_F64
 
-// u = w0 - V (W^H v) - W (V^H v), w = tau u + alpha v -> panel column j of W.  Rows and terms are laid out
-// as in col1.
+// u = w0 - V (W^H v) - W (V^H v), w = tau u + alpha v -> panel column j of W, with w0 summed from the partial vectors of
+// col2 (fixed order: the chunks of the row's block, then the block rows from its own downwards).  One 64-row block of the
+// tile grid per workgroup; the terms of a row are split over the four waves as in col1.
 __global__ void __launch_bounds__(256)
-herm_col3_kernel(const c128* __restrict__ PV, c128* __restrict__ PW, int n, int i, int j, const c128* __restrict__ w0,
-                 const c128* __restrict__ t, const c128* __restrict__ tau, const c128* __restrict__ cpart, int nh)
+herm_col3_kernel(const c128* __restrict__ PV, c128* __restrict__ PW, int n, int i, int j, const c128* __restrict__ PU,
+                 const c128* __restrict__ PZ, const c128* __restrict__ t, const c128* __restrict__ tau, const c128* __restrict__ cpart, int ns, int hch)
 {
     __shared__ c128 st[2 * HNB];
     __shared__ double sbuf[4];
     __shared__ c128 s_alpha;
     __shared__ c128 sp[4][HR];
+    __shared__ c128 sw[4][HR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 2 * j) st[tid] = t[tid];
     // u^H v = w0^H v - 2 Re sum_k conj(t1_k) t2_k: the partials of col2 and, from thread k < j, its term of the correction
     c128 ds = cmake(0.0, 0.0);
-    for (int q = tid; q < nh; q += 256) ds = cadd(ds, cpart[q]);
+    for (int q = tid; q < ns; q += 256) ds = cadd(ds, cpart[q]);
     if (tid < j) { const c128 a = t[tid], b = t[j + tid]; ds.x -= 2.0 * (a.x * b.x + a.y * b.y); }
     const double dr = block_sum_d(ds.x, sbuf), di = block_sum_d(ds.y, sbuf);       // (the barriers inside also publish st)
     if (tid == 0) {
@@ -204,10 +324,13 @@ herm_col3_kernel(const c128* __restrict__ PV, c128* __restrict__ PW, int n, int 
         const c128 th = cmul(tq, whv);
         s_alpha = cmake(-0.5 * th.x, -0.5 * th.y);
     }
-    const int r = i + 1 + blockIdx.x * HR + lane;                                // rows <= i of a panel column are never read
+    const int b0 = (i + 1) / HTB, nbk = (n + HTB - 1) / HTB;
+    const int B = b0 + blockIdx.x;
+    const int r = B * HTB + lane;
+    const bool on = r > i && r < n;                                              // rows <= i of a panel column are never read
     const int qc = (2 * j + 3) / 4, q0 = wave * qc, q1 = min(2 * j, q0 + qc);
-    c128 p = cmake(0.0, 0.0);
-    if (r < n) {
+    c128 p = cmake(0.0, 0.0), ws = cmake(0.0, 0.0);
+    if (on) {
         auto term = [&](int q) { return (q < j) ? PV[(long)q * n + r] : PW[(long)(q - j) * n + r]; };
         int q = q0;
         for (; q + 8 <= q1; q += 8) {                       // eight terms in flight (see col1)
@@ -218,11 +341,26 @@ herm_col3_kernel(const c128* __restrict__ PV, c128* __restrict__ PW, int n, int 
             for (int u = 0; u < 8; ++u) cfma(p, a[u], st[q + u]);
         }
         for (; q < q1; ++q) cfma(p, term(q), st[q]);
+        // the partial vectors of the matvec
+        const int ncu = (B - b0) / hch + 1, nt = ncu + (nbk - B);
+        const int tc = (nt + 3) / 4, t0 = wave * tc, t1 = min(nt, t0 + tc);
+        auto pv = [&](int q) { return (q < ncu) ? PU[(long)q * n + r] : PZ[(long)(B + q - ncu) * n + r]; };
+        q = t0;
+        for (; q + 8 <= t1; q += 8) {
+            c128 a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = pv(q + u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ws = cadd(ws, a[u]);
+        }
+        for (; q < t1; ++q) ws = cadd(ws, pv(q));
     }
     sp[wave][lane] = p;
+    sw[wave][lane] = ws;
     __syncthreads();
-    if (wave != 0 || r >= n) return;
-    const c128 u = csub(w0[r], cadd(cadd(sp[0][lane], sp[1][lane]), cadd(sp[2][lane], sp[3][lane])));
+    if (wave != 0 || !on) return;
+    const c128 w0 = cadd(cadd(sw[0][lane], sw[1][lane]), cadd(sw[2][lane], sw[3][lane]));
+    const c128 u = csub(w0, cadd(cadd(sp[0][lane], sp[1][lane]), cadd(sp[2][lane], sp[3][lane])));
     c128 w = cmul(tau[i], u);
     cfma(w, s_alpha, PV[(long)j * n + r]);
     PW[(long)j * n + r] = w;
@@ -459,11 +597,13 @@ int maus_herm_tridiag(maus_ctx* c, double* d_out, double* e_out) {
     HermClock clk;
     herm_free(c);
     const size_t nn = (size_t)n * n;
-    c128 *Aw = nullptr, *PV = nullptr, *PW = nullptr, *P2 = nullptr, *Q2 = nullptr, *col = nullptr, *w0 = nullptr, *t = nullptr, *cpart = nullptr;
+    c128 *Aw = nullptr, *PV = nullptr, *PW = nullptr, *P2 = nullptr, *Q2 = nullptr, *col = nullptr, *PU = nullptr, *PZ = nullptr, *t = nullptr, *cpart = nullptr;
     double *part = nullptr, *d = nullptr, *e = nullptr;
     const int nparts_max = (n + HR - 1) / HR;
+    const int nbk = (n + HTB - 1) / HTB, nch_max = (nbk + HCH_MIN - 1) / HCH_MIN;      // tile grid of the matvec
+    auto strips = [](int T, int hch) { int s = 0; for (int tb = 0; tb < T; ++tb) s += tb / hch + 1; return s; };   // workgroups for T block rows
     auto cleanup = [&]() {
-        void* ps[] = {Aw, PV, PW, P2, Q2, col, w0, t, cpart, part, d, e};
+        void* ps[] = {Aw, PV, PW, P2, Q2, col, PU, PZ, t, cpart, part, d, e};
         for (void* p : ps) if (p) (void)hipFree(p);
     };
 #define HERM_ALLOC(ptr, bytes) do { if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { (void)hipGetLastError(); cleanup(); herm_free(c); \
@@ -476,9 +616,10 @@ int maus_herm_tridiag(maus_ctx* c, double* d_out, double* e_out) {
     HERM_ALLOC(P2, sizeof(c128) * (size_t)2 * HNB * n);
     HERM_ALLOC(Q2, sizeof(c128) * (size_t)2 * HNB * n);
     HERM_ALLOC(col, sizeof(c128) * n);
-    HERM_ALLOC(w0, sizeof(c128) * n);
+    HERM_ALLOC(PU, sizeof(c128) * (size_t)nch_max * n);
+    HERM_ALLOC(PZ, sizeof(c128) * (size_t)nbk * n);
     HERM_ALLOC(t, sizeof(c128) * 2 * HNB);
-    HERM_ALLOC(cpart, sizeof(c128) * ((n + 3) / 4));
+    HERM_ALLOC(cpart, sizeof(c128) * (size_t)strips(nbk, HCH_MIN));
     HERM_ALLOC(part, sizeof(double) * nparts_max);
     HERM_ALLOC(d, sizeof(double) * n);
     HERM_ALLOC(e, sizeof(double) * n);
@@ -504,17 +645,27 @@ int maus_herm_tridiag(maus_ctx* c, double* d_out, double* e_out) {
             const int np1 = (m + HR - 1) / HR;
             hipLaunchKernelGGL(herm_col1_kernel, dim3(np1), dim3(256), 0, st, Aw, n, i, j, PV, PW, col, part, d);
             if (mp <= 0) continue;
-            const int nh = (mp + 3) / 4;
-            hipLaunchKernelGGL(herm_col2_kernel, dim3(nh + 2 * j), dim3(256), 0, st, Aw, n, i, j, nh, col, part, np1, PV, PW, c->hq, c->htau, e,
-                               w0, cpart, t);
-            hipLaunchKernelGGL(herm_col3_kernel, dim3((mp + HR - 1) / HR), dim3(256), 0, st, PV, PW, n, i, j, w0, t, c->htau, cpart, nh);
+            const int T = nbk - (i + 1) / HTB;                              // block rows of the tile grid that hold rows > i
+            int hch = HCH_MAX;                                              // T (T + 1) / 2 tiles over ~768 workgroups
+            while (hch > HCH_MIN && strips(T, hch) < 768) hch /= 2;
+            const int ns = strips(T, hch);
+            hipLaunchKernelGGL(herm_col2_kernel, dim3(ns + 2 * j), dim3(64 * HW2), 0, st, Aw, n, i, j, ns, hch, col, part, np1, PV, PW, c->hq, c->htau, e,
+                               PU, PZ, cpart, t);
+            hipLaunchKernelGGL(herm_col3_kernel, dim3(T), dim3(256), 0, st, PV, PW, n, i, j, PU, PZ, t, c->htau, cpart, ns, hch);
         }
         const int r0 = i0 + nb, M = n - r0;
         if (M > 0) {
-            // A22 -= V W^H + W V^H as ONE product [V W] [W V]^H (K = 2 nb), both triangles (the matvecs read full rows)
+            // A22 -= V W^H + W V^H as the product [V W] [W V]^H (K = 2 nb) on the LOWER triangle, which is all the matvecs and
+            // col1 read (round 4): column strips of 1024, each from its diagonal block downwards -- 56 % of the full square's
+            // flops at M = 8192.  (Rounds 2-3 updated both triangles for matvecs that read full rows.)
             hipLaunchKernelGGL(herm_pack_kernel, dim3((unsigned)(((long)M * nb + HT - 1) / HT)), dim3(HT), 0, st, PV, PW, n, r0, nb, P2, Q2);
-            ProfScope ps(c, KC_GEMM, 8.0 * M * (double)M * 2 * nb, 16.0 * ((double)M * 4 * nb + 2.0 * M * M));
-            maus_zgemm_launch(st, M, M, 2 * nb, P2, 2 * nb, 0, Q2, 2 * nb, 0, Aw + (size_t)r0 * n + r0, n, 0, -1.0, 1, 1, 1, false, true);
+            constexpr int SW = 1024;
+            for (int c0 = 0; c0 < M; c0 += SW) {
+                const int w = (M - c0 < SW) ? M - c0 : SW, mr = M - c0;
+                ProfScope ps(c, KC_GEMM, 8.0 * mr * (double)w * 2 * nb, 16.0 * ((double)(mr + w) * 2 * nb + 2.0 * mr * w));
+                maus_zgemm_launch(st, mr, w, 2 * nb, P2 + (size_t)c0 * 2 * nb, 2 * nb, 0, Q2 + (size_t)c0 * 2 * nb, 2 * nb, 0,
+                                  Aw + (size_t)(r0 + c0) * n + r0 + c0, n, 0, -1.0, 1, 1, 1, false, true);
+            }
         }
         err = hipGetLastError();
         if (err == hipSuccess) err = hipEventRecord(ev[panel & 1], st);

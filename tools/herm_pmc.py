@@ -1,6 +1,7 @@
 """HBM traffic of the Hermitian reduction's matvec kernel (csrc/herm.hip, herm_col2_kernel) from two rocprofv3 PMC passes
 (FETCH_SIZE, WRITE_SIZE; units and the gfx950 correction as MI355X_MICROARCH.md prescribes: KB, FETCH doubled) against its
-algorithmic bytes sum_i 16 (n - i - 1)^2 and its time from a kernel trace.
+algorithmic bytes sum_i 8 (n - i - 1) (n - i) -- the lower triangle of the trailing matrix, read once per column (round 4;
+the full square, 16 (n - i - 1)^2, in round 3) -- and its time from a kernel trace.
 
     python tools/herm_pmc.py <n> <fetch_dir> <write_dir> <trace_db>
 """
@@ -27,7 +28,7 @@ for name, s, e in db.execute("select name, start, end from kernels"):
     for k in ("col1", "col2", "col3"):
         if "herm_" + k in name:
             ms[k] = ms.get(k, 0.0) + (e - s) * 1e-6
-alg = sum(16.0 * (n - i - 1) ** 2 for i in range(n - 1))
+alg = sum(8.0 * (n - i - 1) * (n - i) for i in range(n - 1))
 print(f"n = {n}: herm_col2_kernel (Hermitian matvec with the trailing matrix + panel dots), {cnt.get(('col2', 'FETCH_SIZE'), 0)} launches")
 for k in ("col1", "col2", "col3"):
     f = tot.get((k, "FETCH_SIZE"), 0.0) * 1024.0 * 2.0
@@ -37,5 +38,5 @@ for k in ("col1", "col2", "col3"):
     if t > 0:
         line += f", {(f + w) / t / 1e9:6.2f} TB/s by the counters"
     if k == "col2":
-        line += f"; algorithmic matrix bytes {alg / 1e9:.2f} GB = {alg / t / 1e9 if t else 0:.2f} TB/s, traffic / algorithmic = {(f + w) / alg:.2f}"
+        line += f"; algorithmic matrix bytes (lower triangle) {alg / 1e9:.2f} GB = {alg / t / 1e9 if t else 0:.2f} TB/s, traffic / algorithmic = {(f + w) / alg:.2f}"
     print(line)

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04
 mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gpu_herm_eigh.py -x -q -m gpu > $O/herm_tests.txt 2>&1
+timeout -k 10 600 python -m pytest tests/test_gpu_herm_eigh.py tests/test_gpu_n8192.py -x -q -m gpu > $O/herm_tests.txt 2>&1
 echo "pytest rc=$?" >> $O/herm_tests.txt
 tail -4 $O/herm_tests.txt
 grep -q "rc=0" $O/herm_tests.txt || { echo TESTS FAILED; exit 1; }
