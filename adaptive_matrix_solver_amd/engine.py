@@ -956,10 +956,10 @@ class DeviceEngine:
                     pd = None
                     if pert == PERT_MT19937:
                         pd = (rng_start, words, 0, (slot0[F] + 1).astype(np.int32))
-                    st = self.d_lu_solve([run[k] for k in F], shift[F], psi0[F], 0 if is_eig else 1, pert, pd)
+                    st_lu = self.d_lu_solve([run[k] for k in F], shift[F], psi0[F], 0 if is_eig else 1, pert, pd)
                     fb[F] = True
                     ok = ok.copy()
-                    ok[F] = st == 0
+                    ok[F] = st_lu == 0
             bad = np.nonzero(~ok)[0]
             nb = int(bad[0]) if bad.size else len(run)
 

@@ -101,6 +101,44 @@ def test_fast_mode_keeps_stream_and_bookkeeping():
         assert snapshot.rng_digest() == g["rng"], f"iter {it} rng"
 
 
+def test_failed_gmres_attempts_are_retried_as_one_direct_batch(monkeypatch):
+    """AMS:99-103 in batch (engine._solve): GMRES preferred, stream-independent host side ('none' here, 'mt19937' on the
+    device), attempt 0 fails for some candidates -> ONE batched direct solve for exactly those, at the same attempt index; the
+    NumPy stream moves by one rand(N,N) pair per attempt (the failed candidates consumed two)."""
+    from adaptive_matrix_solver_amd.engine import GMRES
+    solver, spec = make_solver("lin24", pert_mode="none", gmres_compat="rtol")
+    solver.problem_knowledge["local_solver_preference"] = GMRES
+    ctx = solver.engine.ctx
+    real_gmres, real_lu = ctx.gmres, ctx.shifted_lu_solve
+    lu_batches, fails = [], []
+
+    def flaky_gmres(slots, shift, psi, rhs_mode, use_j, **kw):
+        info, inner, status = real_gmres(slots, shift, psi, rhs_mode, use_j, **kw)
+        info = np.array(info)
+        info[::3] = 1                                           # every third attempt "does not converge"
+        fails.append(int(np.count_nonzero((info != 0) | (np.asarray(status) != 0))))
+        return info, inner, status
+
+    def counting_lu(slots, *a, **kw):
+        lu_batches.append(len(slots))
+        return real_lu(slots, *a, **kw)
+    monkeypatch.setattr(ctx, "gmres", flaky_gmres)
+    monkeypatch.setattr(ctx, "shifted_lu_solve", counting_lu)
+    n = solver.N_diag
+    active = list(solver.candidates)
+    before = np.random.get_state()
+    solver.step_population()
+    assert len(fails) == 1 and fails[0] >= len(range(0, len(active), 3))
+    assert lu_batches == fails                                  # one direct batch, the failed candidates only
+    assert all(c.local_psi_retries_needed == 0 for c in active)
+    assert all(np.isfinite(c.residual_k) for c in active)
+    after = snapshot.rng_digest()
+    np.random.set_state(before)
+    for _ in range(len(active) + fails[0]):                     # (candidates + failures) x two rand(n, n)
+        np.random.rand(n, n); np.random.rand(n, n)
+    assert snapshot.rng_digest() == after
+
+
 def test_nan_ladder_matches_reference():
     from adaptive_matrix_solver_amd.engine import DeviceEngine
     from adaptive_matrix_solver_amd.solver import ProblemType, SolutionCandidate
