@@ -267,6 +267,7 @@ class DeviceEngine:
         self._free = []
         self._next_slot = 0
         self.store = CandidateStore()           # per-candidate bookkeeping, indexed by slot (candstore.py)
+        self._deferred = None                   # candidates whose host vectors wait for one common transfer
         self.steps_executed = 0
 
     # ---- shared default engine (for stand-alone SolutionCandidate use) ----------------
@@ -363,6 +364,26 @@ class DeviceEngine:
     @staticmethod
     def _slots(cands) -> np.ndarray:
         return np.fromiter(map(_SLOT_OF, cands), dtype=np.int64, count=len(cands))
+
+    def begin_deferred_push(self) -> None:
+        self._deferred = []
+
+    def end_deferred_push(self) -> None:
+        """One pop_put per population array for the candidates constructed since begin_deferred_push (the spawns of
+        AMS:533-549: up to 15 per loop body, one 22 us call each before)."""
+        cands, self._deferred = self._deferred, None
+        if not cands:
+            return
+        from .solver import ProblemType
+        cands = list({id(c): c for c in cands}.values())    # a candidate re-initialised twice is pushed once, with its last vectors
+        slots = self._slots(cands)
+        hv = [c for c in cands if c._hv is not None]
+        if hv:
+            self.ctx.pop_put(POP_X, self._slots(hv), np.stack([c._hv for c in hv]))
+        hu = [c for c in cands if c._hu is not None and c.problem_type == ProblemType.SVD]
+        if hu:
+            self.ctx.pop_put(POP_U, self._slots(hu), np.stack([c._hu for c in hu]))
+        self.store.dev_valid[slots] = True
 
     def _bulk_pull(self, cands, slots=None) -> None:
         """Refresh stale host mirrors of many candidates with one transfer per array."""

@@ -529,6 +529,10 @@ class SolutionCandidate:
 
     def _push(self, force=False):
         if force or not self._dev_valid:
+            if self._engine._deferred is not None:          # inside MAUS_Solver's spawn loop: pushed with the others (engine.end_deferred_push)
+                self._engine._deferred.append(self)
+                self._dev_valid = False
+                return
             ctx = self._engine.ctx
             if self._hv is not None:
                 ctx.pop_put(POP_X, [self._slot], self._hv)
@@ -900,13 +904,26 @@ class MAUS_Solver:
         if ix.size < max(2, self.gram_min):
             return None, None
         conv = [self.candidates[k] for k in ix.tolist()]
-        for k in np.nonzero(~st.dev_valid[slots[ix]])[0].tolist():
+        stale = np.nonzero(~st.dev_valid[slots[ix]])[0].tolist()
+        for k in stale:
             conv[k]._push()                              # host-side edits (if any) reach the device rows first
+        # The block of the previous call serves this one when its candidates are a subset (AMS:504-527 retires, the diagnostics
+        # of the next iteration look at the survivors: same vectors -- a CONVERGED candidate is not stepped again -- and the same
+        # products, entry for entry).  Keyed by candidate id; a host-side edit of a vector (a push above) drops it.
+        cache = self.__dict__.get("_gram_cache")
+        if cache is not None and not stale:
+            pos = cache[0]
+            sel = [pos.get(c.id, -1) for c in conv]
+            if min(sel) >= 0:
+                sel = np.asarray(sel, dtype=np.int64)
+                blocks = {k: b[np.ix_(sel, sel)] for k, b in cache[1].items()}
+                return {id(c): i for i, c in enumerate(conv)}, blocks
         eng = self.engine
         if self.problem_type == ProblemType.EIGENVALUE:
             blocks = {"v": np.abs(eng.d_gram(conv, POP_X, self.N_diag))}
         else:
             blocks = {"u": np.abs(eng.d_gram(conv, POP_U, self.N_rows)), "v": np.abs(eng.d_gram(conv, POP_X, self.N_cols))}
+        self._gram_cache = ({c.id: i for i, c in enumerate(conv)}, blocks)
         return {id(c): i for i, c in enumerate(conv)}, blocks
 
     def _update_global_diagnostics(self, iteration):
@@ -1135,22 +1152,26 @@ class MAUS_Solver:
             desired_pop_base = max(desired_pop_base, int(target * 2.5))
         num_to_spawn = max(0, desired_pop_base - len(self.candidates)) + max(0, target - self.num_distinct_converged_solutions)
         num_to_spawn = min(int(num_to_spawn * self.strat_params["spawn_rate_multiplier"]), self.N_diag * 2, 15)
-        for _ in range(max(0, num_to_spawn)):
-            kw = {}
-            if self.num_distinct_converged_solutions > 0 and self.landscape_energy < 0.8 and self.converged_solutions:
-                base_sol_tuple = random.choice(self.converged_solutions)                       # E7
-                if base_sol_tuple is None or any(p is None for p in base_sol_tuple):
-                    continue
-                if self.problem_type == ProblemType.EIGENVALUE:
-                    kw["initial_lambda"] = base_sol_tuple[0] + (random.random() * 0.1 - 0.05 + 1j * (random.random() * 0.1 - 0.05)) * (0.1 + self.landscape_energy)
-                    v_pert = (np.random.rand(self.N_diag) - 0.5 + 1j * (np.random.rand(self.N_diag) - 0.5)) * (0.1 + self.landscape_energy)
-                    new_v = base_sol_tuple[1] + v_pert
-                    norm_new_v = np.linalg.norm(new_v)
-                    kw["initial_v"] = new_v / norm_new_v if norm_new_v > 1e-9 else \
-                        (np.random.rand(self.N_diag) + 1j * np.random.rand(self.N_diag)) / np.sqrt(self.N_diag)
-            new_candidate = self._new_candidate(**kw, initial_weight=0.01)
-            new_candidate.alpha_local_step = GLOBAL_DEFAULT_ALPHA_V_INITIAL * (1 + self.strat_params["overall_psi_aggression_factor"] / 10.0)
-            self.candidates.append(new_candidate)
+        self.engine.begin_deferred_push()                   # the spawns' vectors reach the device in one transfer
+        try:
+            for _ in range(max(0, num_to_spawn)):
+                kw = {}
+                if self.num_distinct_converged_solutions > 0 and self.landscape_energy < 0.8 and self.converged_solutions:
+                    base_sol_tuple = random.choice(self.converged_solutions)                       # E7
+                    if base_sol_tuple is None or any(p is None for p in base_sol_tuple):
+                        continue
+                    if self.problem_type == ProblemType.EIGENVALUE:
+                        kw["initial_lambda"] = base_sol_tuple[0] + (random.random() * 0.1 - 0.05 + 1j * (random.random() * 0.1 - 0.05)) * (0.1 + self.landscape_energy)
+                        v_pert = (np.random.rand(self.N_diag) - 0.5 + 1j * (np.random.rand(self.N_diag) - 0.5)) * (0.1 + self.landscape_energy)
+                        new_v = base_sol_tuple[1] + v_pert
+                        norm_new_v = np.linalg.norm(new_v)
+                        kw["initial_v"] = new_v / norm_new_v if norm_new_v > 1e-9 else \
+                            (np.random.rand(self.N_diag) + 1j * np.random.rand(self.N_diag)) / np.sqrt(self.N_diag)
+                new_candidate = self._new_candidate(**kw, initial_weight=0.01)
+                new_candidate.alpha_local_step = GLOBAL_DEFAULT_ALPHA_V_INITIAL * (1 + self.strat_params["overall_psi_aggression_factor"] / 10.0)
+                self.candidates.append(new_candidate)
+        finally:
+            self.engine.end_deferred_push()
         cache = self.__dict__.get("_view_cache")
         if cache is not None and cache[0] is self.candidates and len(cache[1]) < len(self.candidates):
             born = np.asarray([c._slot for c in self.candidates[len(cache[1]):]], dtype=np.int64)
