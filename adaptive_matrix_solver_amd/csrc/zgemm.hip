@@ -578,9 +578,6 @@ void maus_zgemm_launch_rows(hipStream_t st, int M, int N, int K, const c128* A, 
     // 8MNK-equivalent TFLOP/s): every one-workgroup-per-CU shape (128 x 64 / 128 x 128, BK 16 / 32, software-pipelined or not)
     // stays at 50-59 -- with all waves of a SIMD in one workgroup they run in lockstep and every wait or barrier of one is a
     // bubble for all; 8-wave workgroups lose to 4-wave ones at equal tile area.  The variants that lost those sweeps are gone.
-#ifndef MAUS_ZGEMM_BIG_MIN
-#define MAUS_ZGEMM_BIG_MIN 1536
-#endif
     constexpr int DMA_KMIN = 64;
     if (blay == 0 && !conja && !conjb) {
         // plain layout (row-major LU workspaces of the GMRES path, host-matrix entry points).  Skinny shapes keep the workgroup
@@ -592,7 +589,7 @@ void maus_zgemm_launch_rows(hipStream_t st, int M, int N, int K, const c128* A, 
         // workgroups per CU 88.7 on large updates (86.3 at 1024 x 1056: the 64 x 32 form is kept below 1536).  Same summation
         // order as the register-staged kernel, hence the same bits.
         if (M > 32 && (K % 8) == 0 && K >= DMA_KMIN) {
-            if (M >= MAUS_ZGEMM_BIG_MIN && N >= MAUS_ZGEMM_BIG_MIN) launch_dma<2, 3, 2, 2>(ARGS);   // 64 x 64 tiles, three workgroups per CU
+            if (M >= 1536 && N >= 1536) launch_dma<2, 3, 2, 2>(ARGS);   // 64 x 64 tiles, three workgroups per CU
             else launch_dma<2, 5, 2, 1>(ARGS);
             return;
         }

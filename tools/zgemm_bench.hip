@@ -6,6 +6,8 @@
 //   tools/bin/zgemm_bench M N K ld batch [iters] [zero] [shared]
 //       zero    all-zero operands (clock check: the chip holds a higher clock on zeros)
 //       shared  every matrix reads the same A and B (traffic check)
+//       pop     a population product  C[M,N] = A[M,K] * op(B):  `pop` alone B as [N][K] (dot-product layout, the matvec Y = X A^T of
+//               AMS:264 / 295), `pop plain` B as [K][N]; `conja` / `conjb` conjugate an operand.  One matrix (batch = 1), ld ignored.
 //       lu      the LU's own operand form: tile-major H / U arrays of npad = M + K rows (luws.h), A and C rows through a row list
 //               (identity; `perm`: a random permutation of the rows below K, as implicit pivoting leaves them)
 // Prints ms per launch and 8MNK-equivalent TFLOP/s.  The kernels come straight from the library's translation unit.
@@ -31,6 +33,32 @@ int main(int argc, char** argv) {
     const int iters = argc > 6 ? atoi(argv[6]) : 5;
     bool zero = false, shared = false, lu = false, permute = false;
     for (int i = 7; i < argc; ++i) { zero |= !strcmp(argv[i], "zero"); shared |= !strcmp(argv[i], "shared"); lu |= !strcmp(argv[i], "lu"); permute |= !strcmp(argv[i], "perm"); }
+    bool pop = false, plain = false, conja = false, conjb = false;
+    for (int i = 7; i < argc; ++i) { pop |= !strcmp(argv[i], "pop"); plain |= !strcmp(argv[i], "plain"); conja |= !strcmp(argv[i], "conja"); conjb |= !strcmp(argv[i], "conjb"); }
+    if (pop) {
+        c128 *A = nullptr, *B = nullptr, *C = nullptr;
+        CK(hipMalloc((void**)&A, sizeof(c128) * (size_t)M * K));
+        CK(hipMalloc((void**)&B, sizeof(c128) * (size_t)N * K));
+        CK(hipMalloc((void**)&C, sizeof(c128) * (size_t)M * N));
+        hipStream_t st; CK(hipStreamCreate(&st));
+        hipLaunchKernelGGL(fill_rand_kernel, dim3(2048), dim3(256), 0, st, (double*)A, (size_t)M * K * 2, 12345u);
+        hipLaunchKernelGGL(fill_rand_kernel, dim3(2048), dim3(256), 0, st, (double*)B, (size_t)N * K * 2, 777u);
+        const int blay = plain ? 0 : 1;
+        auto launch = [&]() { maus_zgemm_launch(st, M, N, K, A, K, 0, B, plain ? N : K, 0, C, N, 0, 1.0, 0, 1, blay, conja, conjb); };
+        launch();
+        CK(hipStreamSynchronize(st));
+        hipEvent_t t0, t1; CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
+        CK(hipEventRecord(t0, st));
+        for (int i = 0; i < iters; ++i) launch();
+        CK(hipEventRecord(t1, st));
+        CK(hipEventSynchronize(t1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, t0, t1));
+        ms /= iters;
+        CK(hipGetLastError());
+        printf("M=%d N=%d K=%d pop%s%s%s: %.3f ms per launch, %.1f TFLOP/s (8MNK)\n", M, N, K, plain ? " plain" : "", conja ? " conja" : "", conjb ? " conjb" : "",
+               ms, 8.0 * M * N * K / (ms * 1e-3) / 1e12);
+        return 0;
+    }
     if (lu) {
         // H[rows[m]][K + n] -= H[rows[m]][k] * U[k][K + n]: the first trailing update of a matrix of npad = M + K rows, N <= M + 32
         const int npad = M + K;
