@@ -58,6 +58,21 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Sum over the 64 lanes on the DPP network, the same value in every lane, in a fixed order: four steps inside each row of 16
+// lanes (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: the lanes of a half already agree, so a mirror adds the
+// other half), then the four rows.  wave_sum above goes through ds_bpermute six times.
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+#define MAUS_DPP_F64S(CTRL) __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false), \
+                                             __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false))
+    v += MAUS_DPP_F64S(0xB1);
+    v += MAUS_DPP_F64S(0x4E);
+    v += MAUS_DPP_F64S(0x141);
+    v += MAUS_DPP_F64S(0x140);
+#undef MAUS_DPP_F64S
+    auto lane_f64 = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
+    return (lane_f64(0) + lane_f64(16)) + (lane_f64(32) + lane_f64(48));
+}
+
 // Pivot search inside one wave (LAPACK izamax: largest value, lowest index among equals): on return every lane holds the wave's
 // (best, bidx).  Values are >= 0 or -1 ("no row"), never NaN.  Two reductions on the DPP network -- the maximum of the values,
 // then the minimum index among the lanes that hold it -- instead of six butterfly rounds through ds_bpermute (three LDS-crossbar

@@ -986,64 +986,76 @@ trsm_mfma_kernel(const c128* __restrict__ Hg, c128* __restrict__ Ug, long stride
 // 32-row blocks from the bottom: dot products of the U row tails against x (LDS), then a
 // 32x32 triangle solved by one wave.  Writes x[0..n) to W[slot]; flags bit1 <- non-finite x.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(512)
 backsolve_kernel(const c128* __restrict__ Hg, long ld, long strideH, int n, int npad,
                  c128* __restrict__ Wg, long ldw, const int* __restrict__ slots, c128* __restrict__ xout_dense,
                  int* __restrict__ flags)
 {
-    extern __shared__ c128 sx[];          // npad entries of x, then a 32x33 diagonal block, then 32 rhs
+    extern __shared__ c128 sx[];          // npad entries of x, then a 32x33 diagonal block, then 2 x 32 partial sums
     c128* sD = sx + npad;
-    c128* sR = sD + BSB * (BSB + 1);
+    c128* sP = sD + BSB * (BSB + 1);           // 2 x 32 partial sums of the block's rows
     const int g = blockIdx.x;
     const c128* H = Hg + (long)g * strideH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     bool bad = false;
     for (int i0 = npad - BSB; i0 >= 0; i0 -= BSB) {
         const int jt = i0 + BSB;          // tail starts here
-        // rhs_i = y_i - U[i, jt:] . x[jt:]  ; 16 waves x 2 rows.  Both rows of a wave and four 64-column tiles are in
-        // flight together (eight independent loads per lane): with one row and one tile at a time a small batch -- one
-        // workgroup per matrix, few workgroups on the chip -- waited out every load's latency (5.6 ms per 32-solve call).
-        {
-            static_assert(BSB / 16 == 2, "two rows per wave");
-            const int ia = i0 + wave * 2;
-            const c128* ra = H + (long)ia * ld;                    // tile-major (luws.h): + tile offset of the column
-            const c128* rb = ra + ld;
-            double sar[2] = {0.0, 0.0}, sai[2] = {0.0, 0.0}, sbr[2] = {0.0, 0.0}, sbi[2] = {0.0, 0.0};
-            const int t_lo = jt >> 6, t_hi = (npad + 63) >> 6;
-#pragma unroll 2
-            for (int t = t_lo; t < t_hi; t += 2) {
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const int j = ((t + p) << 6) + lane;
-                    if (j >= jt && j < npad) {
-                        const long off = ((long)(t + p) * npad << 6) + lane;
-                        const c128 ua = ra[off], ub = rb[off], xv = sx[j];
-                        sar[p] = fma(ua.x, xv.x, sar[p]); sar[p] = fma(-ua.y, xv.y, sar[p]);
-                        sai[p] = fma(ua.x, xv.y, sai[p]); sai[p] = fma(ua.y, xv.x, sai[p]);
-                        sbr[p] = fma(ub.x, xv.x, sbr[p]); sbr[p] = fma(-ub.y, xv.y, sbr[p]);
-                        sbi[p] = fma(ub.x, xv.y, sbi[p]); sbi[p] = fma(ub.y, xv.x, sbi[p]);
-                    }
-                }
-            }
-            const double s0 = wave_sum(sar[0] + sar[1]), s1 = wave_sum(sai[0] + sai[1]);
-            const double s2 = wave_sum(sbr[0] + sbr[1]), s3 = wave_sum(sbi[0] + sbi[1]);
-            if (lane == 0) {
-                const long yo = lu_tile_off(npad, npad);
-                const c128 ya = ra[yo], yb = rb[yo];
-                sR[ia - i0] = cmake(ya.x - s0, ya.y - s1);
-                sR[ia - i0 + 1] = cmake(yb.x - s2, yb.y - s3);
-            }
-        }
+        // rhs_i = y_i - U[i, jt:] . x[jt:] for the block's 32 rows.  Round 4 (later): the 8 waves are four row groups of 8 rows
+        // times two column groups (tiles t = t_lo + cg, + 2, ..), every lane with the 8 rows of FOUR tiles in flight at once
+        // (32 loads), and the partial sums meet in LDS.  Rounds 1-3 gave each of 16 waves two rows and the whole tail: 16
+        // dependent iterations of 8 loads at a tail of 2048 columns where this makes 4 of 32, and the chain of 128 blocks is
+        // what a call of few matrices waits for (3.9 ms at any batch below ~100; at 181 the kernel is HBM-bound either way).
+        // (the diagonal block is requested first: its latency passes behind the tail products)
         for (int e = tid; e < BSB * BSB; e += blockDim.x) {
             int r = e / BSB, c = e % BSB;
             sD[r * (BSB + 1) + c] = H[lu_tile_off(npad, i0 + c) + (long)(i0 + r) * ld];
         }
+        {
+            static_assert(BSB == 32, "four row groups of 8");
+            const int rg = wave & 3, cg = wave >> 2;
+            const c128* rbase = H + (long)(i0 + 8 * rg) * ld;             // tile-major (luws.h): + tile offset of the column
+            c128 acc[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = cmake(0.0, 0.0);
+            const int t_lo = jt >> 6, t_hi = (npad + 63) >> 6;
+            for (int t = t_lo + cg; t < t_hi; t += 8) {
+                c128 u[4][8], xv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tq = t + 2 * q, j = (tq << 6) + lane;
+                    const bool ok = tq < t_hi && j >= jt && j < npad;
+                    xv[q] = ok ? sx[j] : cmake(0.0, 0.0);
+                    const long off = ((long)tq * npad << 6) + lane;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) u[q][r] = ok ? rbase[(long)r * ld + off] : cmake(0.0, 0.0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) cfma(acc[r], u[q][r], xv[q]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const double sr = wave_sum_dpp(acc[r].x), si = wave_sum_dpp(acc[r].y);
+                if (lane == 0) sP[cg * BSB + 8 * rg + r] = cmake(sr, si);
+            }
+        }
         __syncthreads();
         if (wave == 0) {
-            c128 rv = (lane < BSB) ? sR[lane] : cmake(0.0, 0.0);
+            c128 rv = cmake(0.0, 0.0), dinv = cmake(0.0, 0.0);
+            if (lane < BSB) {
+                const c128 sum = cadd(sP[lane], sP[BSB + lane]);
+                const c128 y = H[(long)(i0 + lane) * ld + lu_tile_off(npad, npad)];
+                rv = cmake(y.x - sum.x, y.y - sum.y);
+                dinv = crecip(sD[lane * (BSB + 1) + lane]);      // all 32 diagonal entries inverted at once: the substitution
+            }                                                     // below multiplies (rounds 1-3 divided, one division chain per row)
+            // 32 dependent steps: the lane index of the broadcast is a compile-time constant (v_readlane, not ds_bpermute)
+#pragma unroll
             for (int j = BSB - 1; j >= 0; --j) {
-                c128 xj = cdiv(rv, sD[j * (BSB + 1) + j]);        // meaningful on lane j only
-                xj.x = __shfl(xj.x, j, 64); xj.y = __shfl(xj.y, j, 64);
+                c128 xj = cmul(rv, dinv);                         // meaningful on lane j only
+                xj.x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xj.x), j), __builtin_amdgcn_readlane(__double2loint(xj.x), j));
+                xj.y = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xj.y), j), __builtin_amdgcn_readlane(__double2loint(xj.y), j));
                 if (lane == j) sx[i0 + j] = xj;
                 if (lane < j) cfms(rv, sD[lane * (BSB + 1) + j], xj);
             }
@@ -1180,13 +1192,13 @@ void maus_lu_factor(const LuWs& w, int nbo) {
 
 void maus_lu_backsolve(const LuWs& w, c128* Wpop, long ldw, const int* d_slots, c128* xout_dense) {
     prof(w, KC_BACKSOLVE, 0);
-    size_t shm = sizeof(c128) * ((size_t)w.npad + BSB * (BSB + 1) + BSB);
+    size_t shm = sizeof(c128) * ((size_t)w.npad + BSB * (BSB + 1) + 2 * BSB);
     static bool attr_set = false;
     if (!attr_set) {   // ~83 KB of dynamic LDS at npad = 4096, 145 KB at 8192 (160 KB per CU on gfx950)
         (void)hipFuncSetAttribute((const void*)backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(backsolve_kernel, dim3(w.G), dim3(1024), shm, w.st, w.U, (long)LU_TW, w.strideH, w.n, w.npad,
+    hipLaunchKernelGGL(backsolve_kernel, dim3(w.G), dim3(512), shm, w.st, w.U, (long)LU_TW, w.strideH, w.n, w.npad,
                        Wpop, ldw, d_slots, xout_dense, w.flags);
     prof(w, KC_BACKSOLVE, 1, 4.0 * w.npad * w.npad * w.G, 8.0 * w.npad * w.npad * w.G);
 }
