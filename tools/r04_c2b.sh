@@ -1,13 +1,9 @@
-# round 4: configs[1] after the two-window jump kernel + tile-shape check of the K >= 256 updates at n = 1024 shapes
+# round 4: configs[1] after the two-window jump kernel (the tile-shape check of the K >= 256 updates that ran here used a temporary build switch: profiles/r04_population_products.txt)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04
 T=${1:-c2b}
 mkdir -p $O
 timeout -k 10 300 python -m pytest tests/test_gpu_mt19937.py -x -q > $O/${T}_tests.txt 2>&1; tail -3 $O/${T}_tests.txt
-for shape in "512 544 512 1088 256" "256 288 256 1088 256" "768 800 256 1088 256" "1024 1056 512 2112 181" "512 3616 512 4160 64" "3584 544 512 4160 64"; do
-  for b in zgemm_bench zgemm_bench_big; do echo -n "$b: "; timeout -k 10 60 tools/bin/$b $shape 5; done
-done > $O/${T}_tiles.txt 2>&1
-cat $O/${T}_tiles.txt
 LU_N=1024 LU_BATCH_KERNELS=1 timeout -k 10 200 python tools/lu_batch_rates.py 32 256 > $O/${T}_rates.txt 2>&1; cat $O/${T}_rates.txt
 rm -rf $O/trace && mkdir -p $O/trace
 LU_N=1024 timeout -k 10 300 rocprofv3 --kernel-trace -d $O/trace -o t -- python3 tools/lu_batch_rates.py 256 > $O/${T}_trace.out 2>&1
