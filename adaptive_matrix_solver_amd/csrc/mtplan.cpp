@@ -28,8 +28,11 @@ int maus_mt_plan(const maus_mt_desc* d, int n, int first, int g, int s_override,
     // further sub-stream costs a jump, i.e. as much LDS traffic as generating 3300 blocks -- at n = 1024 a whole draw -- and
     // at 256 candidates of n = 1024 eight sub-streams instead of four cost 2048 more jumps (0.96 ms) for the same 1.7 ms of
     // H build (round 4: 21.0 -> 20.1 ms per 256-solve call).  Each sub-stream at least ~64 blocks long.
+    // Small batches of large matrices go on to 64 sub-streams (32 candidates at n = 4096: 32 instead of 16 -> H build 4.9 -> 3.4 ms,
+    // the call 109.0 -> 107.5; at n = 1024 the extra jumps would cost more than the build gains).
+    const int s_cap = (n >= 2048) ? 64 : 16;
     int S = 1;
-    while (2 * S <= 16 && (long)S * std::max(1, g) < 1024) S *= 2;
+    while (2 * S <= s_cap && (long)S * std::max(1, g) < 1024) S *= 2;
     const uint64_t nn = (uint64_t)n * n;
     while (S > 1 && nn / S < 64 * 312) --S;
     if (s_override > 0) S = std::max(1, std::min(64, s_override));
