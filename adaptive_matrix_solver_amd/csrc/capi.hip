@@ -167,6 +167,20 @@ int upload_slots(maus_ctx* c, const int* slots, int count) {
     return 0;
 }
 
+// ---- which rows of Y still hold A X (see ctx.h) ----------------------------------------------------------------------------
+// Every entry point that writes X or Y, changes A or re-allocates the population drops all stamps (a new epoch); maus_pop_put
+// on X drops the rows it writes; maus_residual (SVD) stamps the rows it has just computed; maus_svd_power_propose skips the
+// product for stamped rows.  Read-only entry points (pop_get, hist_*, gram, profile) leave the stamps alone.
+static inline void av_drop_all(maus_ctx* c) { maus_av_drop_all(c); }
+static inline void av_drop(maus_ctx* c, const int* slots, int count) {
+    for (int k = 0; k < count; ++k) if (slots[k] >= 0 && (size_t)slots[k] < c->av_stamp.size()) c->av_stamp[slots[k]] = 0;
+}
+static inline void av_mark(maus_ctx* c, const int* slots, int count) {
+    if (c->av_stamp.size() < (size_t)c->cap) c->av_stamp.resize(c->cap, 0u);
+    for (int k = 0; k < count; ++k) c->av_stamp[slots[k]] = c->av_epoch;
+}
+static inline bool av_has(const maus_ctx* c, int slot) { return (size_t)slot < c->av_stamp.size() && c->av_stamp[slot] == c->av_epoch; }
+
 // profiling hook handed to the LU driver
 void prof_tick(void* ud, int klass, int phase, double flops, double bytes) {
     maus_ctx* c = (maus_ctx*)ud;
@@ -279,6 +293,7 @@ static void free_population(maus_ctx* c) {
 // room for a rows x cols problem matrix; everything that belonged to the previous one goes (also called by comm.hip for the
 // ranks that receive the matrix device to device)
 int maus_matrix_reserve(maus_ctx* c, int rows, int cols) {
+    av_drop_all(c);
     if (rows <= 0 || cols <= 0) FAIL(c, "maus_set_matrix: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->st));
@@ -325,6 +340,7 @@ int maus_get_eigvecs(maus_ctx* c, double* v_out, int n) {
 int maus_pop_capacity(maus_ctx* c) { return c->cap; }
 
 int maus_pop_reserve(maus_ctx* c, int capacity) {
+    av_drop_all(c);
     if (c->rows <= 0) FAIL(c, "maus_pop_reserve: set the matrix first");
     if (capacity <= c->cap) return 0;
     HIPCHK(c, hipStreamSynchronize(c->st));
@@ -366,6 +382,7 @@ static bool contiguous(const int* slots, int count) {
 // hipMemcpy is registered with the driver -- when NumPy later frees it, the next submission of this process waits for the
 // driver's invalidation work (4-40 ms of idle GPU inside somebody's loop body).
 int maus_pop_put(maus_ctx* c, int which, const int* slots, int count, const double* host, int len) {
+    if (which == MAUS_POP_X) av_drop(c, slots, count); else if (which == MAUS_POP_Y) av_drop_all(c);
     c128* P = pop_array(c, which);
     if (!P) FAIL(c, "maus_pop_put: population not reserved / bad array id");
     if (len <= 0 || len > c->ldp) FAIL(c, "maus_pop_put: bad vector length");
@@ -453,6 +470,7 @@ __global__ void copy_rows_kernel(c128* __restrict__ dst, const c128* __restrict_
 }
 
 int maus_pop_device_ptr(maus_ctx* c, int which, void** ptr_out, long* ld_out, int* capacity_out) {
+    av_drop_all(c);
     c128* P = pop_array(c, which);
     if (!P || !ptr_out) FAIL(c, "maus_pop_device_ptr: population not reserved / bad arguments");
     HIPCHK(c, hipStreamSynchronize(c->st));          // the caller is about to touch the rows from another stream
@@ -463,6 +481,7 @@ int maus_pop_device_ptr(maus_ctx* c, int which, void** ptr_out, long* ld_out, in
 }
 
 int maus_pop_copy(maus_ctx* c, int which_dst, int which_src, const int* slots, int count) {
+    av_drop_all(c);
     c128* D = pop_array(c, which_dst); c128* S = pop_array(c, which_src);
     if (!D || !S || D == S) FAIL(c, "maus_pop_copy: population not reserved / bad array ids");
     if (count == 0) return 0;
@@ -563,6 +582,7 @@ static void matvec_into_Y(maus_ctx* c, const c128* src, int count) {
 }
 
 int maus_matvec_rayleigh(maus_ctx* c, const int* slots, int count, double* num, double* den) {
+    av_drop_all(c);
     if (!c->A || !c->X) FAIL(c, "maus_matvec_rayleigh: matrix/population missing");
     if (c->rows != c->cols) FAIL(c, "maus_matvec_rayleigh: square matrix required");
     if (count == 0) return 0;
@@ -787,6 +807,7 @@ static int mt_prepare_and_build(maus_ctx* c, const LuWs& w, const maus_mt_desc* 
 
 int maus_shifted_lu_solve(maus_ctx* c, const int* slots, int count, const double* shift, const double* psi,
                           int rhs_mode, int pert_mode, const void* pert_data, int32_t* status) {
+    av_drop_all(c);
     if (!c->A || !c->X) FAIL(c, "maus_shifted_lu_solve: matrix/population missing");
     if (c->rows != c->cols) FAIL(c, "maus_shifted_lu_solve: square matrix required");
     if (rhs_mode == 1 && (!c->b || c->bn != c->rows)) FAIL(c, "maus_shifted_lu_solve: rhs b not set");
@@ -932,6 +953,7 @@ int maus_set_shared_device(maus_ctx* c, int shared) { if (!c) return -1; c->shar
 int maus_lu_mw_aborts(maus_ctx* c) { return c ? c->mw_aborts : -1; }
 
 int maus_relax_normalise(maus_ctx* c, const int* slots, int count, const double* alpha, int normalise, double* norm_out) {
+    av_drop_all(c);
     if (!c->X) FAIL(c, "maus_relax_normalise: population missing");
     if (count == 0) return 0;
     if (upload_slots(c, slots, count)) return -1;
@@ -945,6 +967,7 @@ int maus_relax_normalise(maus_ctx* c, const int* slots, int count, const double*
 }
 
 int maus_residual(maus_ctx* c, int kind, const int* slots, int count, const double* lam, double* resid, int32_t* finite) {
+    av_drop_all(c);
     if (!c->A || !c->X) FAIL(c, "maus_residual: matrix/population missing");
     if (count == 0) return 0;
     if (upload_slots(c, slots, count)) return -1;
@@ -967,6 +990,7 @@ int maus_residual(maus_ctx* c, int kind, const int* slots, int count, const doub
           maus_zgemm_launch_idx(c->st, count, c->cols, c->rows, c->U, c->ldp, 0, c->A, c->cols, 0, c->W, c->ldp, 0,
                                 1.0, 0, 1, 0, false, true, c->d_slots, c->d_slots); }
         maus_launch_svd_resid(c->st, c->W, c->X, c->ldp, c->d_slots, count, c->cols, c->d_c1, c->d_r1, 1, c->d_i1);
+        av_mark(c, slots, count);                        // Y = A X of these rows stands until somebody writes X or Y
     } else FAIL(c, "maus_residual: unknown kind");
     if (maus_d2h(c, resid, c->d_r1, sizeof(double) * count, c->st)) return -1;
     if (maus_d2h(c, finite, c->d_i1, sizeof(int) * count, c->st)) return -1;
@@ -985,8 +1009,23 @@ int maus_svd_power_propose(maus_ctx* c, const int* slots, int count, double* nor
     if (upload_slots(c, slots, count)) return -1;
     // ||v_in||
     maus_launch_norm(c->st, c->X, c->ldp, c->d_slots, count, c->cols, c->d_r1, 4, 0);
-    // t = A v -> Y ; sigma1 = ||t|| ; u = t / (sigma1 > 1e-10 ? sigma1 : 1), in place
-    matvec_into_Y(c, c->X, count);
+    // t = A v -> Y ; sigma1 = ||t|| ; u = t / (sigma1 > 1e-10 ? sigma1 : 1), in place.
+    // Round 4 (later): the rows whose Y the residual of the previous loop body left behind (same v, same product, same kernel
+    // family: the same bits) are not multiplied again -- at BASELINE configs[4] that is all but the ~15 spawns of a body, one of
+    // the four products of a loop body.  A handful of rows is topped up to 33 so that the partial product takes the DMA 3M
+    // kernels like the full one (per-element arithmetic does not depend on the tile shape: tests/test_gpu_kernels.py).
+    {
+        std::vector<int> need;
+        for (int k = 0; k < count; ++k) if (!av_has(c, slots[k])) need.push_back(slots[k]);
+        if ((int)need.size() == count || count <= 32) matvec_into_Y(c, c->X, count);
+        else if (!need.empty()) {
+            for (int k = 0; k < count && need.size() < 33; ++k) if (av_has(c, slots[k])) need.push_back(slots[k]);
+            if (upload_slots(c, need.data(), (int)need.size())) return -1;
+            matvec_into_Y(c, c->X, (int)need.size());
+            if (upload_slots(c, slots, count)) return -1;
+        }
+        av_drop_all(c);                                  // Y becomes u below
+    }
     maus_launch_norm_scale(c->st, c->Y, c->Y, c->ldp, c->d_slots, count, c->rows, c->d_r1, 4, 1);
     maus_launch_norm(c->st, c->Y, c->ldp, c->d_slots, count, c->rows, c->d_r1, 4, 2);
     // s = A^H u -> W ; sigma2 = ||s|| ; v = s / (sigma2 > 1e-10 ? sigma2 : 1), in place
@@ -1000,6 +1039,7 @@ int maus_svd_power_propose(maus_ctx* c, const int* slots, int count, double* nor
 }
 
 int maus_svd_commit(maus_ctx* c, const int* slots, int count) {
+    av_drop_all(c);
     if (!c->X) FAIL(c, "maus_svd_commit: population missing");
     if (count == 0) return 0;
     if (upload_slots(c, slots, count)) return -1;
@@ -1015,6 +1055,7 @@ int maus_svd_power_step(maus_ctx* c, const int* slots, int count, double* norms_
 }
 
 int maus_herm_match(maus_ctx* c, const int* slots, int count, int32_t* idx_out, double* norm_out) {
+    av_drop_all(c);
     if (!c->V || !c->X) FAIL(c, "maus_herm_match: eigenvectors/population missing");
     if (count == 0) return 0;
     if (upload_slots(c, slots, count)) return -1;
@@ -1052,6 +1093,7 @@ int maus_gram(maus_ctx* c, int which, const int* slots, int count, int len, doub
 
 int maus_gmres(maus_ctx* c, const int* slots, int count, const double* shift, const double* psi, int rhs_mode,
                const int32_t* use_jacobi, double rtol, int restart, int maxiter, int32_t* info_out, int32_t* inner_out, int32_t* status) {
+    av_drop_all(c);
     return maus_gmres_run(c, slots, count, shift, psi, rhs_mode, use_jacobi, rtol, restart, maxiter, info_out, inner_out, status,
                           nullptr, 0, 0, nullptr);
 }
@@ -1059,6 +1101,7 @@ int maus_gmres(maus_ctx* c, const int* slots, int count, const double* shift, co
 int maus_gmres_pert(maus_ctx* c, const int* slots, int count, const double* shift, const double* psi, int rhs_mode,
                     const int32_t* want_jacobi, int pert_mode, const void* pert_data, double rtol, int restart, int maxiter,
                     int32_t* info_out, int32_t* inner_out, int32_t* status, int32_t* jacobi_out) {
+    av_drop_all(c);
     if (!c->A || !c->X) FAIL(c, "maus_gmres_pert: matrix/population missing");
     if (c->rows != c->cols) FAIL(c, "maus_gmres_pert: square matrix required");
     if (rhs_mode == 1 && (!c->b || c->bn != c->rows)) FAIL(c, "maus_gmres_pert: rhs b not set");

@@ -179,6 +179,7 @@ int maus_comm_allgather_records(maus_ctx* c, const void* send, size_t bytes_per_
 // owners' rows are packed, all-gathered device to device and scattered into the population array `which` of every rank:
 // one pack kernel, one ncclAllGather over xGMI, one unpack kernel -- 16 MB per step at n = 4096 / 256 candidates.
 int maus_comm_allgather_rows(maus_ctx* c, int which, const int* slots, const int* counts, int len) {
+    maus_av_drop_all(c);                                 // rows of X change under the products kept in Y (capi.hip: av_*)
     if (!c->comm) FAIL(c, "maus_comm_allgather_rows: no communicator (maus_comm_init)");
     c128* P = pop_array(c, which);
     if (!P) FAIL(c, "maus_comm_allgather_rows: population not reserved / bad array id");

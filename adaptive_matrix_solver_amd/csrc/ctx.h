@@ -5,6 +5,7 @@
 
 #include <map>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 // ---- kernels / drivers implemented in the other translation units ---------------------
@@ -61,6 +62,10 @@ struct maus_ctx {
     // per-call scalar staging (device), sized for `scal_cap` candidates
     int scal_cap = 0;
     int *d_slots = nullptr, *d_i1 = nullptr, *d_i2 = nullptr;
+    // Y[slot] = A X[slot] is known to hold for the slots stamped with the current epoch (capi.hip: av_*): the SVD residual of one
+    // loop body leaves the product that the power step of the next one starts with (AMS:295-298 / 228)
+    std::vector<uint32_t> av_stamp;
+    uint32_t av_epoch = 1;
     c128 *d_c1 = nullptr, *d_c2 = nullptr;
     double *d_r1 = nullptr, *d_r2 = nullptr;
     // LU workspace
@@ -126,6 +131,8 @@ int ensure_scalars(maus_ctx* c, int count);
 int ensure_scratch(maus_ctx* c, size_t bytes);
 int check_slots(maus_ctx* c, const int* slots, int count);
 int upload_slots(maus_ctx* c, const int* slots, int count);
+// no row of Y is known to hold A X any more (see maus_ctx::av_stamp)
+inline void maus_av_drop_all(maus_ctx* c) { if (++c->av_epoch == 0) { c->av_epoch = 1; std::fill(c->av_stamp.begin(), c->av_stamp.end(), 0u); } }
 // Host <-> device copies of anything larger than a few KB go through the context's pinned buffer, never straight from / into the
 // caller's memory (capi.hip).  Both are synchronous with respect to `st`.
 int maus_pin_ready(maus_ctx* c);

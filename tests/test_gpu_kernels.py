@@ -140,3 +140,64 @@ def test_empty_and_minimal_inputs(ctx):
             assert np.allclose(W[k], ref, rtol=1e-13, atol=1e-14)
         num, den = ctx.matvec_rayleigh([0, 1, 2])
         assert np.allclose(num, np.einsum("ki,ki->k", V.conj(), V @ A.T)) and np.allclose(den, np.einsum("ki,ki->k", V.conj(), V))
+
+
+def test_population_product_rows_do_not_depend_on_the_batch(ctx):
+    """A row of Y = X A^T has the same bits whether it is computed among 1600 rows (64 x 64 tiles of the DMA 3M kernel), among
+    40 (64 x 32 tiles) or among 33: per-element arithmetic does not depend on the tile shape.  maus_svd_power_propose relies on it
+    when it multiplies only the rows whose product is not at hand (AMS:228 / 295-298)."""
+    from adaptive_matrix_solver_amd._cabi import POP_X
+    POP_Y = 3
+    rng = np.random.default_rng(7)
+    n, P = 1536, 1600
+    A = ((rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) / np.sqrt(n)).astype(np.complex128)
+    X = (rng.standard_normal((P, n)) + 1j * rng.standard_normal((P, n))).astype(np.complex128)
+    ctx.set_matrix(A)
+    ctx.pop_reserve(P)
+    ctx.pop_put(POP_X, np.arange(P), X)
+    ctx.matvec_rayleigh(np.arange(P))
+    sel = np.array([5, 77, 640, 641, 1203, 1599] + list(range(100, 134)))          # 40 rows
+    big = ctx.pop_get(POP_Y, sel, n)
+    assert np.abs(big - X[sel] @ A.T).max() <= 1e-11
+    for m in (40, 33):
+        ctx.matvec_rayleigh(sel[:m])
+        assert np.array_equal(ctx.pop_get(POP_Y, sel[:m], n), big[:m]), m
+
+
+def test_svd_power_step_reuses_the_residuals_product_bit_for_bit():
+    """Two contexts walk the same SVD loop bodies (propose / commit / residual, AMS:227-255 + 295-298); in one of them every
+    product is recomputed (the stamps that say 'Y = A X for this row' are dropped before each propose), in the other the power
+    step multiplies only the rows that changed since the residual -- here a few re-seeded rows per body, like the spawns of
+    AMS:533-549.  Norms, residuals and vectors must agree bit for bit."""
+    from adaptive_matrix_solver_amd import Context
+    from adaptive_matrix_solver_amd._cabi import KIND_SVD, POP_U, POP_W, POP_X
+    rng = np.random.default_rng(11)
+    rows, cols, P = 384, 320, 200
+    A = ((rng.standard_normal((rows, cols)) + 1j * rng.standard_normal((rows, cols))) / 16).astype(np.complex128)
+    V0 = (rng.standard_normal((P, cols)) + 1j * rng.standard_normal((P, cols))).astype(np.complex128)
+    U0 = (rng.standard_normal((P, rows)) + 1j * rng.standard_normal((P, rows))).astype(np.complex128)
+    fresh = [(rng.standard_normal((7, cols)) + 1j * rng.standard_normal((7, cols))).astype(np.complex128) for _ in range(4)]
+    out = []
+    for reuse in (False, True):
+        c = Context(0)
+        try:
+            c.set_matrix(A)
+            c.pop_reserve(P)
+            sl = np.arange(P)
+            c.pop_put(POP_X, sl, V0); c.pop_put(POP_U, sl, U0)
+            rec = []
+            for body in range(4):
+                if not reuse:
+                    c.pop_copy(POP_W, POP_X, [])                  # any writing entry point drops the stamps (no row is copied)
+                norms = c.svd_power_propose(sl)
+                c.svd_commit(sl)
+                sig = np.maximum(norms[:, 1], norms[:, 3]).astype(np.complex128)
+                res, fin = c.residual(KIND_SVD, sl, sig)
+                rec.append((norms.copy(), np.asarray(res).copy()))
+                c.pop_put(POP_X, np.arange(3 + body, 3 + body + 7), fresh[body])     # seven rows change before the next body
+            rec.append((c.pop_get(POP_X, sl, cols), c.pop_get(POP_U, sl, rows)))
+            out.append(rec)
+        finally:
+            c.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
