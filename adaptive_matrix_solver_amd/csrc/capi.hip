@@ -180,6 +180,16 @@ static inline void av_mark(maus_ctx* c, const int* slots, int count) {
     for (int k = 0; k < count; ++k) c->av_stamp[slots[k]] = c->av_epoch;
 }
 static inline bool av_has(const maus_ctx* c, int slot) { return (size_t)slot < c->av_stamp.size() && c->av_stamp[slot] == c->av_epoch; }
+// the same for S = A^H U (ctx.h): stamped by maus_svd_commit for the rows whose u it has just installed, dropped with Y's stamps
+// and by maus_pop_put on U
+static inline void ahu_drop(maus_ctx* c, const int* slots, int count) {
+    for (int k = 0; k < count; ++k) if (slots[k] >= 0 && (size_t)slots[k] < c->ahu_stamp.size()) c->ahu_stamp[slots[k]] = 0;
+}
+static inline void ahu_mark(maus_ctx* c, const int* slots, int count) {
+    if (c->ahu_stamp.size() < (size_t)c->cap) c->ahu_stamp.resize(c->cap, 0u);
+    for (int k = 0; k < count; ++k) c->ahu_stamp[slots[k]] = c->ahu_epoch;
+}
+static inline bool ahu_has(const maus_ctx* c, int slot) { return c->S && (size_t)slot < c->ahu_stamp.size() && c->ahu_stamp[slot] == c->ahu_epoch; }
 
 // profiling hook handed to the LU driver
 void prof_tick(void* ud, int klass, int phase, double flops, double bytes) {
@@ -244,7 +254,7 @@ int maus_ctx_destroy(maus_ctx* c) {
     (void)hipStreamSynchronize(c->st);
     (void)maus_comm_destroy(c);
     void* ptrs[] = {c->A, c->b, c->V, c->X, c->U, c->W, c->Y, c->d_slots, c->d_i1, c->d_i2, c->d_c1, c->d_c2, c->d_r1, c->d_r2,
-                    c->H, c->ipiv, c->perm, c->mw_sync, c->info, c->flags, c->Upert, c->scratch, c->hq, c->htau, c->hz};
+                    c->H, c->ipiv, c->perm, c->mw_sync, c->info, c->flags, c->Upert, c->scratch, c->hq, c->htau, c->hz, c->S};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pin_small) (void)hipHostFree(c->pin_small);
@@ -382,7 +392,7 @@ static bool contiguous(const int* slots, int count) {
 // hipMemcpy is registered with the driver -- when NumPy later frees it, the next submission of this process waits for the
 // driver's invalidation work (4-40 ms of idle GPU inside somebody's loop body).
 int maus_pop_put(maus_ctx* c, int which, const int* slots, int count, const double* host, int len) {
-    if (which == MAUS_POP_X) av_drop(c, slots, count); else if (which == MAUS_POP_Y) av_drop_all(c);
+    if (which == MAUS_POP_X) av_drop(c, slots, count); else if (which == MAUS_POP_U) ahu_drop(c, slots, count); else if (which == MAUS_POP_Y) av_drop_all(c);
     c128* P = pop_array(c, which);
     if (!P) FAIL(c, "maus_pop_put: population not reserved / bad array id");
     if (len <= 0 || len > c->ldp) FAIL(c, "maus_pop_put: bad vector length");
@@ -967,6 +977,9 @@ int maus_relax_normalise(maus_ctx* c, const int* slots, int count, const double*
 }
 
 int maus_residual(maus_ctx* c, int kind, const int* slots, int count, const double* lam, double* resid, int32_t* finite) {
+    // (SVD) does S hold A^H u for every row asked for?  Decided before the stamps go: this call rewrites Y
+    bool have_ahu = (kind == MAUS_SVD) && count > 0;
+    for (int k = 0; have_ahu && k < count; ++k) have_ahu = slots[k] >= 0 && ahu_has(c, slots[k]);
     av_drop_all(c);
     if (!c->A || !c->X) FAIL(c, "maus_residual: matrix/population missing");
     if (count == 0) return 0;
@@ -985,11 +998,14 @@ int maus_residual(maus_ctx* c, int kind, const int* slots, int count, const doub
         // ||A v - s u||  : Y = X * A^T  (count x rows)
         matvec_into_Y(c, c->X, count);
         maus_launch_svd_resid(c->st, c->Y, c->U, c->ldp, c->d_slots, count, c->rows, c->d_c1, c->d_r1, 0, c->d_i1);
-        // ||A^H u - s v||: W = U * conj(A)  (count x cols), B = conj(A) as [k=rows][n=cols]
-        { ProfScope ps(c, KC_GEMM, 8.0 * count * c->rows * c->cols, 16.0 * (double)c->rows * c->cols);
-          maus_zgemm_launch_idx(c->st, count, c->cols, c->rows, c->U, c->ldp, 0, c->A, c->cols, 0, c->W, c->ldp, 0,
-                                1.0, 0, 1, 0, false, true, c->d_slots, c->d_slots); }
-        maus_launch_svd_resid(c->st, c->W, c->X, c->ldp, c->d_slots, count, c->cols, c->d_c1, c->d_r1, 1, c->d_i1);
+        // ||A^H u - s v||: W = U * conj(A)  (count x cols), B = conj(A) as [k=rows][n=cols] -- or, when the power step of this
+        // loop body has left exactly that product in S (same u, same kernel, same bits), no product at all (round 4)
+        if (!have_ahu) {
+            ProfScope ps(c, KC_GEMM, 8.0 * count * c->rows * c->cols, 16.0 * (double)c->rows * c->cols);
+            maus_zgemm_launch_idx(c->st, count, c->cols, c->rows, c->U, c->ldp, 0, c->A, c->cols, 0, c->W, c->ldp, 0,
+                                  1.0, 0, 1, 0, false, true, c->d_slots, c->d_slots);
+        }
+        maus_launch_svd_resid(c->st, have_ahu ? c->S : c->W, c->X, c->ldp, c->d_slots, count, c->cols, c->d_c1, c->d_r1, 1, c->d_i1);
         av_mark(c, slots, count);                        // Y = A X of these rows stands until somebody writes X or Y
     } else FAIL(c, "maus_residual: unknown kind");
     if (maus_d2h(c, resid, c->d_r1, sizeof(double) * count, c->st)) return -1;
@@ -1029,23 +1045,37 @@ int maus_svd_power_propose(maus_ctx* c, const int* slots, int count, double* nor
     maus_launch_norm_scale(c->st, c->Y, c->Y, c->ldp, c->d_slots, count, c->rows, c->d_r1, 4, 1);
     maus_launch_norm(c->st, c->Y, c->ldp, c->d_slots, count, c->rows, c->d_r1, 4, 2);
     // s = A^H u -> W ; sigma2 = ||s|| ; v = s / (sigma2 > 1e-10 ? sigma2 : 1), in place
+    // (the unscaled product stays in S: the residual of this loop body asks for A^H u of the same u, AMS:298)
+    if (c->Scap < c->cap) {
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        if (c->S) { (void)hipFree(c->S); c->S = nullptr; c->Scap = 0; }
+        HIPCHK(c, hipMalloc((void**)&c->S, sizeof(c128) * (size_t)c->cap * c->ldp));
+        c->Scap = c->cap;
+    }
     { ProfScope ps(c, KC_GEMM, 8.0 * count * c->rows * c->cols, 16.0 * (double)c->rows * c->cols);
-      maus_zgemm_launch_idx(c->st, count, c->cols, c->rows, c->Y, c->ldp, 0, c->A, c->cols, 0, c->W, c->ldp, 0,
+      maus_zgemm_launch_idx(c->st, count, c->cols, c->rows, c->Y, c->ldp, 0, c->A, c->cols, 0, c->S, c->ldp, 0,
                             1.0, 0, 1, 0, false, true, c->d_slots, c->d_slots); }
-    maus_launch_norm_scale(c->st, c->W, c->W, c->ldp, c->d_slots, count, c->cols, c->d_r1, 4, 3);
+    maus_launch_norm_scale(c->st, c->S, c->W, c->ldp, c->d_slots, count, c->cols, c->d_r1, 4, 3);
+    if (++c->prop_epoch == 0) { c->prop_epoch = 1; std::fill(c->prop_stamp.begin(), c->prop_stamp.end(), 0u); }
+    if (c->prop_stamp.size() < (size_t)c->cap) c->prop_stamp.resize(c->cap, 0u);
+    for (int k = 0; k < count; ++k) c->prop_stamp[slots[k]] = c->prop_epoch;
     if (maus_d2h(c, norms_out, c->d_r1, sizeof(double) * 4 * count, c->st)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->st));
     return 0;
 }
 
 int maus_svd_commit(maus_ctx* c, const int* slots, int count) {
-    av_drop_all(c);
+    if (++c->av_epoch == 0) { c->av_epoch = 1; std::fill(c->av_stamp.begin(), c->av_stamp.end(), 0u); }     // X changes; S stays what it is
     if (!c->X) FAIL(c, "maus_svd_commit: population missing");
     if (count == 0) return 0;
     if (upload_slots(c, slots, count)) return -1;
     hipLaunchKernelGGL(copy_rows_kernel, dim3(count), dim3(256), 0, c->st, c->U, c->Y, c->ldp, c->d_slots, c->rows);
     hipLaunchKernelGGL(copy_rows_kernel, dim3(count), dim3(256), 0, c->st, c->X, c->W, c->ldp, c->d_slots, c->cols);
     HIPCHK(c, hipStreamSynchronize(c->st));
+    // U is now the u whose A^H u the latest proposal left in S -- for the rows that proposal covered
+    if (c->ahu_stamp.size() < (size_t)c->cap) c->ahu_stamp.resize(c->cap, 0u);
+    for (int k = 0; k < count; ++k)
+        if ((size_t)slots[k] < c->prop_stamp.size() && c->prop_stamp[slots[k]] == c->prop_epoch) c->ahu_stamp[slots[k]] = c->ahu_epoch;
     return 0;
 }
 

@@ -66,6 +66,12 @@ struct maus_ctx {
     // loop body leaves the product that the power step of the next one starts with (AMS:295-298 / 228)
     std::vector<uint32_t> av_stamp;
     uint32_t av_epoch = 1;
+    // S[slot] = A^H U[slot], the unscaled second product of the SVD power step (AMS:240), kept for the residual of the same loop
+    // body (AMS:298: the same product of the same u); allocated by the first power step; stamps as for Y
+    c128* S = nullptr;
+    int Scap = 0;
+    std::vector<uint32_t> ahu_stamp, prop_stamp;   // prop_stamp: rows of the latest proposal (S holds A^H of ITS u until committed)
+    uint32_t ahu_epoch = 1, prop_epoch = 1;
     c128 *d_c1 = nullptr, *d_c2 = nullptr;
     double *d_r1 = nullptr, *d_r2 = nullptr;
     // LU workspace
@@ -132,7 +138,10 @@ int ensure_scratch(maus_ctx* c, size_t bytes);
 int check_slots(maus_ctx* c, const int* slots, int count);
 int upload_slots(maus_ctx* c, const int* slots, int count);
 // no row of Y is known to hold A X any more (see maus_ctx::av_stamp)
-inline void maus_av_drop_all(maus_ctx* c) { if (++c->av_epoch == 0) { c->av_epoch = 1; std::fill(c->av_stamp.begin(), c->av_stamp.end(), 0u); } }
+inline void maus_av_drop_all(maus_ctx* c) {
+    if (++c->av_epoch == 0) { c->av_epoch = 1; std::fill(c->av_stamp.begin(), c->av_stamp.end(), 0u); }
+    if (++c->ahu_epoch == 0) { c->ahu_epoch = 1; std::fill(c->ahu_stamp.begin(), c->ahu_stamp.end(), 0u); }
+}
 // Host <-> device copies of anything larger than a few KB go through the context's pinned buffer, never straight from / into the
 // caller's memory (capi.hip).  Both are synchronous with respect to `st`.
 int maus_pin_ready(maus_ctx* c);

@@ -318,6 +318,12 @@ def run_other_config(args):
         "step_flops_algorithmic": step_flops,
         "step_tflops": step_flops * steps_done / elapsed / 1e12,
         "step_frac_of_mfma_peak": step_flops * steps_done / elapsed / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+        # what reaches the matrix pipe: 3M products (0.75), and for the SVD step two of the reference's four products per
+        # candidate step -- the power step takes A v from the previous residual and the residual A^H u from the power step
+        # (the same products of the same vectors, bit for bit: csrc/capi.hip av_* / ahu_*)
+        "step_frac_of_mfma_peak_executed": (0.75 * (0.5 if kind == "svd" else 1.0)) * step_flops * steps_done / elapsed / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+        **({"step_note": "algorithmic flops count the reference's four products per SVD step (AMS:228, 240, 295, 298); two are executed"}
+           if kind == "svd" else {}),
     }
     if kind == "lin":
         out["gmres"] = {"calls": gm["calls"], "candidate_solves": gm["cands"], "inner_iterations_mean": gm["inner"] / max(1, gm["cands"])}
@@ -357,7 +363,8 @@ def run_side_configs(args):
                "per_step_ms": [x["ms"] for x in d["per_step"]], "per_step_active": [x["active"] for x in d["per_step"]],
                "roofline": {"bound": r["bound"], "kernel": r["kernel"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
                             "frac": r["frac"], "kernel_time_share": r.get("kernel_time_share")},
-               "step_frac_of_mfma_peak": d["step_frac_of_mfma_peak"], "kernel_ms_profiled_pass": d["kernel_ms_profiled_pass"],
+               "step_frac_of_mfma_peak": d["step_frac_of_mfma_peak"], "step_frac_of_mfma_peak_executed": d.get("step_frac_of_mfma_peak_executed"),
+               **({"step_note": d["step_note"]} if "step_note" in d else {}), "kernel_ms_profiled_pass": d["kernel_ms_profiled_pass"],
                "solver_build_s": d["config"]["solver_build_s"], "wall_s_of_this_side_run": round(time.perf_counter() - t0, 1)}
         if "gmres" in d:
             ent["gmres"] = d["gmres"]

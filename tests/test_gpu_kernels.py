@@ -166,9 +166,10 @@ def test_population_product_rows_do_not_depend_on_the_batch(ctx):
 
 def test_svd_power_step_reuses_the_residuals_product_bit_for_bit():
     """Two contexts walk the same SVD loop bodies (propose / commit / residual, AMS:227-255 + 295-298); in one of them every
-    product is recomputed (the stamps that say 'Y = A X for this row' are dropped before each propose), in the other the power
-    step multiplies only the rows that changed since the residual -- here a few re-seeded rows per body, like the spawns of
-    AMS:533-549.  Norms, residuals and vectors must agree bit for bit."""
+    product is recomputed (the stamps that say 'Y = A X for this row' / 'S = A^H U for this row' are dropped before each propose
+    and each residual), in the other the power step multiplies only the rows that changed since the residual -- here a few
+    re-seeded rows per body, like the spawns of AMS:533-549 -- and the residual takes A^H u from the power step.  Norms,
+    residuals and vectors must agree bit for bit."""
     from adaptive_matrix_solver_amd import Context
     from adaptive_matrix_solver_amd._cabi import KIND_SVD, POP_U, POP_W, POP_X
     rng = np.random.default_rng(11)
@@ -192,6 +193,8 @@ def test_svd_power_step_reuses_the_residuals_product_bit_for_bit():
                 norms = c.svd_power_propose(sl)
                 c.svd_commit(sl)
                 sig = np.maximum(norms[:, 1], norms[:, 3]).astype(np.complex128)
+                if not reuse:
+                    c.pop_copy(POP_W, POP_X, [])                  # ... and the stamps of the power step's own A^H u
                 res, fin = c.residual(KIND_SVD, sl, sig)
                 rec.append((norms.copy(), np.asarray(res).copy()))
                 c.pop_put(POP_X, np.arange(3 + body, 3 + body + 7), fresh[body])     # seven rows change before the next body
