@@ -1036,9 +1036,12 @@ int maus_svd_power_propose(maus_ctx* c, const int* slots, int count, double* nor
         if ((int)need.size() == count || count <= 32) matvec_into_Y(c, c->X, count);
         else if (!need.empty()) {
             for (int k = 0; k < count && need.size() < 33; ++k) if (av_has(c, slots[k])) need.push_back(slots[k]);
-            if (upload_slots(c, need.data(), (int)need.size())) return -1;
-            matvec_into_Y(c, c->X, (int)need.size());
-            if (upload_slots(c, slots, count)) return -1;
+            if (need.size() < 33) matvec_into_Y(c, c->X, count);          // (cannot happen with count > 32; kept for the invariant)
+            else {
+                if (upload_slots(c, need.data(), (int)need.size())) return -1;
+                matvec_into_Y(c, c->X, (int)need.size());
+                if (upload_slots(c, slots, count)) return -1;
+            }
         }
         av_drop_all(c);                                  // Y becomes u below
     }
