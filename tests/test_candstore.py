@@ -147,3 +147,48 @@ def test_population_view_follows_the_candidate_list():
     assert list(s._pop_view()[1]) == [c._slot for c in s.candidates]
     s.candidates.pop(0)
     assert list(s._pop_view()[1]) == [c._slot for c in s.candidates]
+
+
+def SolutionCandidateState():
+    from adaptive_matrix_solver_amd.solver import SolutionCandidate
+    return SolutionCandidate.State
+
+
+def test_spawns_reach_the_device_in_one_transfer_and_the_gram_block_is_reused(monkeypatch):
+    """AMS:533-549 constructs up to 15 candidates per loop body; their vectors are pushed together.  The Gram block of
+    _manage_candidates serves the diagnostics of the next iteration (its CONVERGED set is a subset), and a host-side edit of a
+    converged vector drops it."""
+    s, spec, _ = _solver("herm16")                             # Hermitian: the shortcut converges every stepped candidate (AMS:155-181)
+    ctx = s.engine.ctx
+    puts, grams = [], []
+    real_put, real_gram = ctx.pop_put, ctx.gram
+
+    def put(which, slots, vecs):
+        puts.append(len(list(slots)))
+        return real_put(which, slots, vecs)
+
+    def gram(which, slots, length):
+        grams.append(len(list(slots)))
+        return real_gram(which, slots, length)
+    s.gram_min = 2
+    CONV = SolutionCandidateState().CONVERGED
+    it = 0
+    while sum(c.state is CONV for c in s.candidates) < 3:      # loop bodies until a few candidates have converged
+        it += 1
+        assert it < 10
+        s.loop_body(it)
+    s._update_global_diagnostics(it + 1); s._adjust_global_strategy(it + 1); s.step_population()
+    monkeypatch.setattr(ctx, "pop_put", put)
+    monkeypatch.setattr(ctx, "gram", gram)
+    ids_before = {c.id for c in s.candidates}
+    s._manage_candidates(it + 1)
+    spawned = [c for c in s.candidates if c.id not in ids_before]
+    assert spawned and puts == [len(spawned)]                  # one transfer for all of them
+    assert all(c._dev_valid for c in spawned)
+    assert len(grams) == 1                                      # the block of the converged set ...
+    s._update_global_diagnostics(it + 2)
+    assert len(grams) == 1                                      # ... serves the next diagnostics (a subset of it)
+    conv = [c for c in s.candidates if c.state is type(c).State.CONVERGED]
+    conv[0].v_k = conv[0].v_k.copy()                            # a host-side edit: pushed again, the block is recomputed
+    s._update_global_diagnostics(it + 3)
+    assert len(grams) == 2
