@@ -254,7 +254,7 @@ int maus_ctx_destroy(maus_ctx* c) {
     (void)hipStreamSynchronize(c->st);
     (void)maus_comm_destroy(c);
     void* ptrs[] = {c->A, c->b, c->V, c->X, c->U, c->W, c->Y, c->d_slots, c->d_i1, c->d_i2, c->d_c1, c->d_c2, c->d_r1, c->d_r2,
-                    c->H, c->ipiv, c->perm, c->mw_sync, c->info, c->flags, c->Upert, c->scratch, c->hq, c->htau, c->hz, c->S};
+                    c->H, c->ipiv, c->perm, c->ident, c->mw_sync, c->info, c->flags, c->Upert, c->scratch, c->hq, c->htau, c->hz, c->S};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pin_small) (void)hipHostFree(c->pin_small);
@@ -632,6 +632,7 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     if (c->H) { (void)hipFree(c->H); c->H = nullptr; }
     if (c->ipiv) { (void)hipFree(c->ipiv); c->ipiv = nullptr; }
     if (c->perm) { (void)hipFree(c->perm); c->perm = nullptr; }
+    if (c->ident) { (void)hipFree(c->ident); c->ident = nullptr; }
     if (c->mw_sync) { (void)hipFree(c->mw_sync); c->mw_sync = nullptr; }
     if (c->info) { (void)hipFree(c->info); c->info = nullptr; }
     if (c->flags) { (void)hipFree(c->flags); c->flags = nullptr; }
@@ -652,6 +653,9 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
     }
     HIPCHK(c, hipMalloc((void**)&c->ipiv, sizeof(int) * (size_t)G * npad));
     HIPCHK(c, hipMalloc((void**)&c->perm, sizeof(int) * (size_t)G * npad));
+    { std::vector<int> id(npad); for (int i = 0; i < npad; ++i) id[i] = i;
+      HIPCHK(c, hipMalloc((void**)&c->ident, sizeof(int) * (size_t)npad));
+      HIPCHK(c, hipMemcpy(c->ident, id.data(), sizeof(int) * (size_t)npad, hipMemcpyHostToDevice)); }
     HIPCHK(c, hipMalloc((void**)&c->mw_sync, maus_lu_mw_sync_bytes() * (size_t)G));
     HIPCHK(c, hipMalloc((void**)&c->info, sizeof(int) * G));
     HIPCHK(c, hipMalloc((void**)&c->flags, sizeof(int) * G));
@@ -667,7 +671,7 @@ static int ensure_lu_ws(maus_ctx* c, int n, int want) {
 static LuWs make_ws(maus_ctx* c, int n, int G) {
     LuWs w;
     w.n = n; w.npad = c->Hnpad; w.ldh = w.npad + 32; w.strideH = (long)w.npad * lu_ntiles(w.npad) * LU_TW; w.G = G;
-    w.H = c->H; w.U = c->H + (size_t)c->Hg * w.strideH; w.perm = c->perm; w.ipiv = c->ipiv; w.info = c->info; w.flags = c->flags; w.st = c->st;
+    w.H = c->H; w.U = c->H + (size_t)c->Hg * w.strideH; w.perm = c->perm; w.ident = c->ident; w.ipiv = c->ipiv; w.info = c->info; w.flags = c->flags; w.st = c->st;
     w.tick = prof_tick; w.ud = c;
     return w;
 }

@@ -81,6 +81,7 @@ struct maus_ctx {
     // after its first rendezvous time-out on this context; mw_aborts counts the batches that were repeated without it
     bool shared_device = false; bool mw_disabled = false; int mw_aborts = 0;
     int *ipiv = nullptr, *perm = nullptr, *info = nullptr, *flags = nullptr; void* mw_sync = nullptr;
+    int* ident = nullptr;                     // 0, 1, .., npad - 1: the row list of products on the logical-order U array (blocked back substitution)
     double* Upert = nullptr; size_t Ubytes = 0;
     // device-side MT19937 regeneration (mtdev.hip)
     // one buffer set per sub-batch stream: the host prepares sub-batch s+1 while the jump / build kernels of sub-batch s

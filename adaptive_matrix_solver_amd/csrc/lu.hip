@@ -987,18 +987,22 @@ trsm_mfma_kernel(const c128* __restrict__ Hg, c128* __restrict__ Ug, long stride
 // 32x32 triangle solved by one wave.  Writes x[0..n) to W[slot]; flags bit1 <- non-finite x.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512)
-backsolve_kernel(const c128* __restrict__ Hg, long ld, long strideH, int n, int npad,
+backsolve_kernel(c128* __restrict__ Hg, long ld, long strideH, int n, int npad,
                  c128* __restrict__ Wg, long ldw, const int* __restrict__ slots, c128* __restrict__ xout_dense,
-                 int* __restrict__ flags)
+                 int* __restrict__ flags, int row_lo, int row_hi)
 {
+    // rows [row_lo, row_hi): the columns from row_hi on have already been taken out of y (blocked form, maus_lu_backsolve), and
+    // x then goes back into the augmented column, where the update of the rows above reads it; the whole matrix in one
+    // launch is row_lo = 0, row_hi = npad
+    const bool whole = (row_lo == 0 && row_hi == npad);
     extern __shared__ c128 sx[];          // npad entries of x, then a 32x33 diagonal block, then 2 x 32 partial sums
     c128* sD = sx + npad;
     c128* sP = sD + BSB * (BSB + 1);           // 2 x 32 partial sums of the block's rows
     const int g = blockIdx.x;
-    const c128* H = Hg + (long)g * strideH;
+    c128* H = Hg + (long)g * strideH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     bool bad = false;
-    for (int i0 = npad - BSB; i0 >= 0; i0 -= BSB) {
+    for (int i0 = row_hi - BSB; i0 >= row_lo; i0 -= BSB) {
         const int jt = i0 + BSB;          // tail starts here
         // rhs_i = y_i - U[i, jt:] . x[jt:] for the block's 32 rows.  Round 4 (later): the 8 waves are four row groups of 8 rows
         // times two column groups (tiles t = t_lo + cg, + 2, ..), every lane with the 8 rows of FOUR tiles in flight at once
@@ -1017,13 +1021,13 @@ backsolve_kernel(const c128* __restrict__ Hg, long ld, long strideH, int n, int 
             c128 acc[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[r] = cmake(0.0, 0.0);
-            const int t_lo = jt >> 6, t_hi = (npad + 63) >> 6;
+            const int t_lo = jt >> 6, t_hi = (row_hi + 63) >> 6;
             for (int t = t_lo + cg; t < t_hi; t += 8) {
                 c128 u[4][8], xv[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int tq = t + 2 * q, j = (tq << 6) + lane;
-                    const bool ok = tq < t_hi && j >= jt && j < npad;
+                    const bool ok = tq < t_hi && j >= jt && j < row_hi;
                     xv[q] = ok ? sx[j] : cmake(0.0, 0.0);
                     const long off = ((long)tq * npad << 6) + lane;
 #pragma unroll
@@ -1056,15 +1060,30 @@ backsolve_kernel(const c128* __restrict__ Hg, long ld, long strideH, int n, int 
                 c128 xj = cmul(rv, dinv);                         // meaningful on lane j only
                 xj.x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xj.x), j), __builtin_amdgcn_readlane(__double2loint(xj.x), j));
                 xj.y = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xj.y), j), __builtin_amdgcn_readlane(__double2loint(xj.y), j));
-                if (lane == j) sx[i0 + j] = xj;
+                if (lane == j) { sx[i0 + j] = xj; if (!whole) H[(long)(i0 + j) * ld + lu_tile_off(npad, npad)] = xj; }
                 if (lane < j) cfms(rv, sD[lane * (BSB + 1) + j], xj);
             }
         }
         __syncthreads();
     }
+    if (!whole) return;
     c128* out = (Wg != nullptr) ? Wg + (long)slots[g] * ldw : xout_dense + (long)g * n;
     for (int i = tid; i < n; i += blockDim.x) { c128 v = sx[i]; bad |= !cfinite(v); out[i] = v; }
     if (__any(bad) && lane == 0) atomicOr(&flags[g], 2);
+}
+
+// x out of the augmented column (blocked back substitution): W[slot] or the dense output, flags bit1 <- non-finite x
+__global__ void __launch_bounds__(256)
+backsolve_out_kernel(const c128* __restrict__ Hg, long ld, long strideH, int n, int npad, c128* __restrict__ Wg, long ldw,
+                     const int* __restrict__ slots, c128* __restrict__ xout_dense, int* __restrict__ flags)
+{
+    const int g = blockIdx.y;
+    const c128* col = Hg + (long)g * strideH + lu_tile_off(npad, npad);
+    c128* out = (Wg != nullptr) ? Wg + (long)slots[g] * ldw : xout_dense + (long)g * n;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
+    if (i < n) { const c128 v = col[(long)i * ld]; bad = !cfinite(v); out[i] = v; }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[g], 2);
 }
 
 }  // namespace
@@ -1198,8 +1217,22 @@ void maus_lu_backsolve(const LuWs& w, c128* Wpop, long ldw, const int* d_slots, 
         (void)hipFuncSetAttribute((const void*)backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         attr_set = true;
     }
+    // Few matrices (round 4, later): one workgroup per matrix draws a single CU's share of the bandwidth -- 134 MB of U per
+    // matrix at ~40 GB/s, 3.3 ms whatever the batch.  Then the substitution runs in blocks of 256 columns: the block's own
+    // triangle by the kernel above (x back into the augmented column), everything above it as ONE product over the whole
+    // batch, y[0 : b0] -= U[0 : b0, block] x_block on the skinny zgemm (N = 1: the chip's bandwidth instead of G CUs').
+    constexpr int BB = 256;                                  // (128 .. 1024 measured: 2.2-2.4 ms at 32 solves either way)
+    if (w.G <= 64 && w.npad >= 2048 && (w.npad % BB) == 0 && w.ident != nullptr) {
+        for (int b0 = w.npad - BB; b0 >= 0; b0 -= BB) {
+            hipLaunchKernelGGL(backsolve_kernel, dim3(w.G), dim3(512), shm, w.st, w.U, (long)LU_TW, w.strideH, w.n, w.npad,
+                               Wpop, ldw, d_slots, xout_dense, w.flags, b0, b0 + BB);
+            if (b0 > 0) maus_zgemm_launch_lu(w.st, b0, 1, BB, w.U, w.U, w.U, w.npad, w.strideH, b0, b0, w.npad, w.G, w.ident, 0);
+        }
+        hipLaunchKernelGGL(backsolve_out_kernel, dim3((w.n + 255) / 256, w.G), dim3(256), 0, w.st, w.U, (long)LU_TW, w.strideH, w.n, w.npad,
+                           Wpop, ldw, d_slots, xout_dense, w.flags);
+    } else
     hipLaunchKernelGGL(backsolve_kernel, dim3(w.G), dim3(512), shm, w.st, w.U, (long)LU_TW, w.strideH, w.n, w.npad,
-                       Wpop, ldw, d_slots, xout_dense, w.flags);
+                       Wpop, ldw, d_slots, xout_dense, w.flags, 0, w.npad);
     prof(w, KC_BACKSOLVE, 1, 4.0 * w.npad * w.npad * w.G, 8.0 * w.npad * w.npad * w.G);
 }
 

@@ -25,6 +25,7 @@ struct LuWs {
     // implicit pivoting: rows never move.  perm[g][i] = physical row of H that holds logical row i; the finished rows of
     // U (and the carried right-hand side) are written in LOGICAL order to the second array U (same ld / stride as H)
     c128* U; int* perm;
+    const int* ident = nullptr;  // identity row list (npad entries), for products whose rows are logical rows of U
     void* mw_sync = nullptr;     // per-matrix rendezvous area of the multi-workgroup panel; null unless this LU is alone on the device
     // multi-workgroup panel: how long a rendezvous may wait (100 MHz ticks) before the matrix is reported as
     // info = INT_MIN (the caller then repeats the batch with one workgroup per matrix), and the test hook that makes one
