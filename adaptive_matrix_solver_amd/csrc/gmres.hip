@@ -225,6 +225,13 @@ gmres_init_kernel(GArgs a) {
     }
 }
 
+// Y[act[first + p]] = Y[act[0]] (see the first product of a linear system in maus_gmres_run)
+__global__ void __launch_bounds__(256)
+bcast_row_kernel(c128* __restrict__ Y, int n, const int* __restrict__ act, int first) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) Y[(long)act[first + blockIdx.y] * n + i] = Y[(long)act[0] * n + i];
+}
+
 // active list + the row of the basis array each active candidate multiplies next
 __global__ void __launch_bounds__(1024)
 gmres_compact_kernel(const GState* __restrict__ st, int count, int rows_per, int R, int* __restrict__ act,
@@ -520,6 +527,15 @@ int maus_gmres_run(maus_ctx* c, const int* slots, int count, const double* shift
         if (Hdense) {
             ProfScope ps(c, KC_VEC, 0, 16.0 * h_nact * (double)n * n);
             hipLaunchKernelGGL(gemv_dense_kernel, dim3((n + 15) / 16, h_nact), dim3(GT), 0, c->st, a, act, zrow);
+        } else
+        if (tick == 0 && rhs_mode == 1 && h_nact > 33) {
+            // The first product of a linear system is A x0 with x0 = b for EVERY candidate (AMS:85: x0 = b; the shift and psi come in
+            // behind the product): 33 rows of it -- enough for the kernel family of the full product, so the same bits (round 4:
+            // tests/test_gpu_kernels.py, rows do not depend on the batch) -- and a copy for the others, instead of the same
+            // row of a 512-row product 512 times.
+            { ProfScope ps(c, KC_GEMM, 8.0 * 33 * (double)n * n, 16.0 * ((double)n * n + 2.0 * 33 * n));
+              maus_zgemm_launch_idx(c->st, 33, n, n, a.Vb, n, 0, c->A, n, 0, a.Y, n, 0, 1.0, 0, 1, 1, false, false, zrow, act); }
+            hipLaunchKernelGGL(bcast_row_kernel, dim3((n + 255) / 256, h_nact - 33), dim3(256), 0, c->st, a.Y, n, act, 33);
         } else
         { ProfScope ps(c, KC_GEMM, 8.0 * h_nact * (double)n * n, 16.0 * ((double)n * n + 2.0 * h_nact * n));
           maus_zgemm_launch_idx(c->st, h_nact, n, n, a.Vb, n, 0, c->A, n, 0, a.Y, n, 0, 1.0, 0, 1, 1, false, false, zrow, act); }
