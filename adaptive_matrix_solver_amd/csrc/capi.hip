@@ -175,7 +175,13 @@ static inline void av_drop_all(maus_ctx* c) { maus_av_drop_all(c); }
 static inline void av_drop(maus_ctx* c, const int* slots, int count) {
     for (int k = 0; k < count; ++k) if (slots[k] >= 0 && (size_t)slots[k] < c->av_stamp.size()) c->av_stamp[slots[k]] = 0;
 }
+// A stamp promises more than "this row holds A x": it promises the bits that a product over MORE than 32 rows on the DMA 3M
+// kernels gives -- what a later, larger call would compute for the row.  Products of up to 32 rows (and of matrices the DMA
+// staging does not take: K not a multiple of 8) run other kernels with another rounding, so they leave no stamps, and reuse is
+// only attempted by calls that are themselves in that family.
+static inline bool av_family(const maus_ctx* c, int count, int K) { return count > 32 && (K % 8) == 0 && K >= 64; }
 static inline void av_mark(maus_ctx* c, const int* slots, int count) {
+    if (!av_family(c, count, c->cols)) return;
     if (c->av_stamp.size() < (size_t)c->cap) c->av_stamp.resize(c->cap, 0u);
     for (int k = 0; k < count; ++k) c->av_stamp[slots[k]] = c->av_epoch;
 }
@@ -591,13 +597,31 @@ static void matvec_into_Y(maus_ctx* c, const c128* src, int count) {
                           1.0, 0, 1, /*blay*/1, false, false, c->d_slots, c->d_slots);
 }
 
+// Y = A X for the rows of `slots` that do not hold it already (stamps: av_*).  The rows whose product an earlier call left in Y
+// (same x, same product, same kernel family: the same bits) are not multiplied again; a handful of missing rows is topped up to
+// 33 so that the partial product takes the DMA 3M kernels like the full one (per-element arithmetic does not depend on the tile
+// shape: tests/test_gpu_kernels.py).  Leaves d_slots = slots.
+static int matvec_missing_into_Y(maus_ctx* c, const int* slots, int count) {
+    std::vector<int> need;
+    for (int k = 0; k < count; ++k) if (!av_has(c, slots[k])) need.push_back(slots[k]);
+    if ((int)need.size() == count || !av_family(c, count, c->cols)) { matvec_into_Y(c, c->X, count); return 0; }
+    if (need.empty()) return 0;
+    for (int k = 0; k < count && need.size() < 33; ++k) if (av_has(c, slots[k])) need.push_back(slots[k]);
+    if (need.size() < 33) { matvec_into_Y(c, c->X, count); return 0; }      // (cannot happen with count > 32; kept for the invariant)
+    if (upload_slots(c, need.data(), (int)need.size())) return -1;
+    matvec_into_Y(c, c->X, (int)need.size());
+    return upload_slots(c, slots, count);
+}
+
 int maus_matvec_rayleigh(maus_ctx* c, const int* slots, int count, double* num, double* den) {
-    av_drop_all(c);
     if (!c->A || !c->X) FAIL(c, "maus_matvec_rayleigh: matrix/population missing");
     if (c->rows != c->cols) FAIL(c, "maus_matvec_rayleigh: square matrix required");
     if (count == 0) return 0;
     if (upload_slots(c, slots, count)) return -1;
-    matvec_into_Y(c, c->X, count);
+    // (the residual of the previous loop body has left A x of the unchanged candidates in Y: AMS:295 / 264)
+    if (matvec_missing_into_Y(c, slots, count)) return -1;
+    av_drop_all(c);
+    av_mark(c, slots, count);                            // Y = A X of these rows stands until somebody writes X or Y
     { ProfScope ps(c, KC_VEC, 0, 32.0 * count * c->rows);
       maus_launch_rayleigh_dots(c->st, c->X, c->Y, c->ldp, c->d_slots, count, c->rows, c->d_c1, c->d_c2); }
     if (maus_d2h(c, num, c->d_c1, sizeof(c128) * count, c->st)) return -1;
@@ -982,7 +1006,7 @@ int maus_relax_normalise(maus_ctx* c, const int* slots, int count, const double*
 
 int maus_residual(maus_ctx* c, int kind, const int* slots, int count, const double* lam, double* resid, int32_t* finite) {
     // (SVD) does S hold A^H u for every row asked for?  Decided before the stamps go: this call rewrites Y
-    bool have_ahu = (kind == MAUS_SVD) && count > 0;
+    bool have_ahu = (kind == MAUS_SVD) && av_family(c, count, c->rows);
     for (int k = 0; have_ahu && k < count; ++k) have_ahu = slots[k] >= 0 && ahu_has(c, slots[k]);
     av_drop_all(c);
     if (!c->A || !c->X) FAIL(c, "maus_residual: matrix/population missing");
@@ -996,6 +1020,7 @@ int maus_residual(maus_ctx* c, int kind, const int* slots, int count, const doub
         matvec_into_Y(c, c->X, count);
         { ProfScope ps(c, KC_VEC, 0, 32.0 * count * c->rows);
           maus_launch_residual(c->st, kind, c->X, c->Y, c->ldp, c->d_slots, count, c->rows, lam ? c->d_c1 : nullptr, c->b, c->d_r1, c->d_i1); }
+        av_mark(c, slots, count);                        // Y = A X of these rows stands until somebody writes X or Y
     } else if (kind == MAUS_SVD) {
         if (!lam) FAIL(c, "maus_residual: sigma missing");
         if (maus_h2d(c, c->d_c1, lam, sizeof(c128) * count, c->st)) return -1;
@@ -1030,25 +1055,10 @@ int maus_svd_power_propose(maus_ctx* c, const int* slots, int count, double* nor
     // ||v_in||
     maus_launch_norm(c->st, c->X, c->ldp, c->d_slots, count, c->cols, c->d_r1, 4, 0);
     // t = A v -> Y ; sigma1 = ||t|| ; u = t / (sigma1 > 1e-10 ? sigma1 : 1), in place.
-    // Round 4 (later): the rows whose Y the residual of the previous loop body left behind (same v, same product, same kernel
-    // family: the same bits) are not multiplied again -- at BASELINE configs[4] that is all but the ~15 spawns of a body, one of
-    // the four products of a loop body.  A handful of rows is topped up to 33 so that the partial product takes the DMA 3M
-    // kernels like the full one (per-element arithmetic does not depend on the tile shape: tests/test_gpu_kernels.py).
-    {
-        std::vector<int> need;
-        for (int k = 0; k < count; ++k) if (!av_has(c, slots[k])) need.push_back(slots[k]);
-        if ((int)need.size() == count || count <= 32) matvec_into_Y(c, c->X, count);
-        else if (!need.empty()) {
-            for (int k = 0; k < count && need.size() < 33; ++k) if (av_has(c, slots[k])) need.push_back(slots[k]);
-            if (need.size() < 33) matvec_into_Y(c, c->X, count);          // (cannot happen with count > 32; kept for the invariant)
-            else {
-                if (upload_slots(c, need.data(), (int)need.size())) return -1;
-                matvec_into_Y(c, c->X, (int)need.size());
-                if (upload_slots(c, slots, count)) return -1;
-            }
-        }
-        av_drop_all(c);                                  // Y becomes u below
-    }
+    // Round 4 (later): the rows whose Y the residual of the previous loop body left behind are not multiplied again
+    // (matvec_missing_into_Y) -- at BASELINE configs[4] that is all but the ~15 spawns of a body, one of the four products of a loop body.
+    if (matvec_missing_into_Y(c, slots, count)) return -1;
+    av_drop_all(c);                                      // Y becomes u below
     maus_launch_norm_scale(c->st, c->Y, c->Y, c->ldp, c->d_slots, count, c->rows, c->d_r1, 4, 1);
     maus_launch_norm(c->st, c->Y, c->ldp, c->d_slots, count, c->rows, c->d_r1, 4, 2);
     // s = A^H u -> W ; sigma2 = ||s|| ; v = s / (sigma2 > 1e-10 ? sigma2 : 1), in place
@@ -1065,7 +1075,7 @@ int maus_svd_power_propose(maus_ctx* c, const int* slots, int count, double* nor
     maus_launch_norm_scale(c->st, c->S, c->W, c->ldp, c->d_slots, count, c->cols, c->d_r1, 4, 3);
     if (++c->prop_epoch == 0) { c->prop_epoch = 1; std::fill(c->prop_stamp.begin(), c->prop_stamp.end(), 0u); }
     if (c->prop_stamp.size() < (size_t)c->cap) c->prop_stamp.resize(c->cap, 0u);
-    for (int k = 0; k < count; ++k) c->prop_stamp[slots[k]] = c->prop_epoch;
+    if (av_family(c, count, c->rows)) for (int k = 0; k < count; ++k) c->prop_stamp[slots[k]] = c->prop_epoch;
     if (maus_d2h(c, norms_out, c->d_r1, sizeof(double) * 4 * count, c->st)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->st));
     return 0;
@@ -1083,6 +1093,7 @@ int maus_svd_commit(maus_ctx* c, const int* slots, int count) {
     if (c->ahu_stamp.size() < (size_t)c->cap) c->ahu_stamp.resize(c->cap, 0u);
     for (int k = 0; k < count; ++k)
         if ((size_t)slots[k] < c->prop_stamp.size() && c->prop_stamp[slots[k]] == c->prop_epoch) c->ahu_stamp[slots[k]] = c->ahu_epoch;
+    // (a proposal of up to 32 rows left no prop stamps: see av_family)
     return 0;
 }
 

@@ -159,9 +159,17 @@ def test_population_product_rows_do_not_depend_on_the_batch(ctx):
     sel = np.array([5, 77, 640, 641, 1203, 1599] + list(range(100, 134)))          # 40 rows
     big = ctx.pop_get(POP_Y, sel, n)
     assert np.abs(big - X[sel] @ A.T).max() <= 1e-11
+    from adaptive_matrix_solver_amd._cabi import POP_W
     for m in (40, 33):
+        ctx.pop_copy(POP_W, POP_X, [])                    # drops the library's "Y = A X" stamps: the product below is really run
+        ctx.pop_put(POP_Y, sel[:m], np.zeros((m, n), dtype=np.complex128))
         ctx.matvec_rayleigh(sel[:m])
         assert np.array_equal(ctx.pop_get(POP_Y, sel[:m], n), big[:m]), m
+    # ... and with the stamps in place it is not: the rows come back as they are
+    marker = np.full((3, n), 7.0 + 1.0j)
+    ctx.pop_put(POP_W, sel[:3], marker)                   # (W is not X or Y: the stamps stay)
+    ctx.matvec_rayleigh(sel[:33])
+    assert np.array_equal(ctx.pop_get(POP_Y, sel[:33], n), big[:33])
 
 
 def test_svd_power_step_reuses_the_residuals_product_bit_for_bit():
@@ -204,3 +212,27 @@ def test_svd_power_step_reuses_the_residuals_product_bit_for_bit():
             c.close()
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_kept_products_never_mix_kernel_families():
+    """A product over up to 32 rows runs other kernels (another rounding) than one over more: the rows it leaves in Y must not
+    be taken for the rows of a later, larger product.  Residual of 30 candidates, then the Rayleigh quotients of those 30 plus
+    10 new ones: bit for bit what a context without any kept product computes."""
+    from adaptive_matrix_solver_amd import Context
+    from adaptive_matrix_solver_amd._cabi import KIND_EIG, POP_X
+    rng = np.random.default_rng(5)
+    n, P = 256, 40
+    A = ((rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) / np.sqrt(n)).astype(np.complex128)
+    X = (rng.standard_normal((P, n)) + 1j * rng.standard_normal((P, n))).astype(np.complex128)
+    lam = (rng.standard_normal(P) + 1j * rng.standard_normal(P)).astype(np.complex128)
+    out = []
+    for warm in (False, True):
+        c = Context(0)
+        try:
+            c.set_matrix(A); c.pop_reserve(P); c.pop_put(POP_X, np.arange(P), X)
+            if warm:
+                c.residual(KIND_EIG, np.arange(30), lam[:30])         # 30 rows: the small-batch kernels
+            out.append(c.matvec_rayleigh(np.arange(P)))
+        finally:
+            c.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
